@@ -1,0 +1,152 @@
+/* libser_hip.so — C ABI of the MI355X (gfx950) multimodal-SER hot path.
+ *
+ * The reference (kananmittal/Multilingual-Multimodal-Speech-Emotion-Recognition) has no FFI seam:
+ * its hot path is the Python module API under src/models/ executed by torch / transformers.  This
+ * header is the seam a maintainer binds instead (ctypes stub shown in INTEGRATION.md).  Every entry
+ * point names the reference interface it replaces (paths relative to the reference root; "hf:" =
+ * transformers 5.15.0 models/).
+ *
+ * Conventions
+ *   - plain C: raw device pointers into caller-owned (torch-owned) storage, sizes, strides.
+ *   - the library never allocates or frees device memory; scratch is a caller-provided workspace
+ *     sized by the matching *_workspace_bytes() call.
+ *   - every launch is asynchronous on the hipStream_t passed as `void* stream`.
+ *   - return 0 (SER_OK) or a negative SER_E_* code; ser_last_error_string() gives the text
+ *     (thread-local).
+ *   - "split bf16": a tensor stored as two bf16 planes hi = bf16(x), lo = bf16(x - hi).  With both
+ *     planes a product costs three bf16 MFMAs and carries ~2^-16 relative error (parity mode); with
+ *     lo == NULL it is one plain bf16 MFMA (fast mode).
+ */
+#ifndef SER_HIP_H
+#define SER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SER_OK 0
+#define SER_E_ARG (-1)
+#define SER_E_HIP (-2)
+#define SER_E_WORKSPACE (-3)
+
+#define SER_ACT_NONE 0
+#define SER_ACT_GELU 1 /* exact erf GELU (hf: activations.py GELUActivation) */
+#define SER_ACT_RELU 2
+#define SER_ACT_TANH 3
+#define SER_ACT_SIGMOID 4
+
+#define SER_PREC_BF16 0   /* one bf16 MFMA per product, fp32 accumulate            */
+#define SER_PREC_BF16X3 1 /* split-bf16 operands, three MFMAs, ~fp32-accurate       */
+
+#define SER_MAX_CONV 8
+
+const char* ser_last_error_string(void);
+int ser_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * op-level entry points (used by the parity tests and composed by the module-level calls)
+ * ------------------------------------------------------------------------------------------- */
+
+/* x[n] fp32 -> hi[n], lo[n] bf16 planes (lo may be NULL). */
+int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long long n, void* stream);
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, split-bf16 operands, fp32 accumulate.
+ * Replaces every torch.nn.Linear / Conv1d-as-GEMM inside the frozen encoders
+ * (hf: wav2vec2/modeling_wav2vec2.py:254-272,429-435,500-572; xlm_roberta/modeling_xlm_roberta.py:211-250,336-398).
+ * K % 64 == 0, lda/ldw % 8 == 0.  Any of c_f32 / (c_hi,c_lo) may be NULL. */
+int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi,
+                     const uint16_t* w_lo, int ldw, int M, int N, int K, const float* bias, int act,
+                     const float* residual, int ldr, float* c_f32, uint16_t* c_hi, uint16_t* c_lo,
+                     int ldc, void* stream);
+
+/* y = LayerNorm(x (+ x2)) * gamma + beta over the last dim D; fp32 in; fp32 and/or split out.
+ * Replaces nn.LayerNorm in hf wav2vec2 :429,:601,:606 and xlm_roberta :336-340,:394-398. */
+int ser_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps,
+                  int rows, int D, float* y_f32, uint16_t* y_hi, uint16_t* y_lo, void* stream);
+
+/* softmax(Q K^T / sqrt(64) + key_bias) V for head_dim 64, Q/K/V read from the fused QKV
+ * projection planes [B*S, 3*H] (q | k | v column blocks).  key_mask [B,S] 1/0 fp32 or NULL.
+ * Replaces hf wav2vec2 :438-463 (eager/sdpa attention) and xlm_roberta :211-250.
+ * ctx planes [B*S, H]. */
+int ser_self_attention(const uint16_t* qkv_hi, const uint16_t* qkv_lo, const float* key_mask, int B,
+                       int S, int heads, uint16_t* ctx_hi, uint16_t* ctx_lo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * frozen encoders, forward only
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint16_t* hi;
+  const uint16_t* lo; /* NULL in SER_PREC_BF16 */
+} SerSplitW;
+
+typedef struct {
+  SerSplitW qkv; /* [3H, H]  rows: q | k | v */
+  const float* qkv_b;
+  SerSplitW o; /* [H, H] */
+  const float* o_b;
+  const float *ln1_g, *ln1_b;
+  SerSplitW f1; /* [F, H] */
+  const float* f1_b;
+  SerSplitW f2; /* [H, F] */
+  const float* f2_b;
+  const float *ln2_g, *ln2_b;
+} SerLayerW;
+
+typedef struct {
+  int hidden, layers, heads, ffn;
+  int n_conv;
+  int conv_dim[SER_MAX_CONV], conv_kernel[SER_MAX_CONV], conv_stride[SER_MAX_CONV];
+  int pos_kernel, pos_groups;
+  float eps;
+} SerW2vConfig;
+
+typedef struct {
+  const float* conv0_w;          /* [C0, k0] fp32 (in_channels = 1)                          */
+  const float *gn_g, *gn_b;      /* GroupNorm(C0 groups) affine                              */
+  SerSplitW conv_w[SER_MAX_CONV];/* i >= 1: [C_i, k_i, C_{i-1}] (channels-last taps)         */
+  const float *fp_ln_g, *fp_ln_b;
+  SerSplitW fp_w;                /* [H, C_last] */
+  const float* fp_b;
+  SerSplitW pos_w;               /* weight-norm folded, [G, H/G, k, H/G]                     */
+  const float* pos_b;            /* [H] */
+  const float *enc_ln_g, *enc_ln_b;
+  const SerLayerW* layers;       /* host array of `layers` records                           */
+} SerW2vWeights;
+
+/* Wav2Vec2Model.forward (eval) on B equal-length raw clips, including the feature extractor's
+ * zero-mean/unit-variance normalisation.  Replaces ref src/models/audio_encoder.py:91-110 =
+ * hf feature_extraction_wav2vec2.py:78-96 + modeling_wav2vec2.py:1319 (409-419, 429-435, 689-727).
+ * wave [B,T] fp32 -> out [B,S,H] fp32 (last_hidden_state). */
+size_t ser_wav2vec2_workspace_bytes(const SerW2vConfig* cfg, int B, int T, int prec);
+int ser_wav2vec2_out_len(const SerW2vConfig* cfg, int T);
+int ser_wav2vec2_forward(const SerW2vConfig* cfg, const SerW2vWeights* w, const float* wave, int B,
+                         int T, int prec, float* out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+typedef struct {
+  int hidden, layers, heads, ffn, vocab, max_pos, pad_id;
+  float eps;
+} SerXlmrConfig;
+
+typedef struct {
+  const float* word_emb; /* [vocab, H] fp32 */
+  const float* pos_emb;  /* [max_pos, H]    */
+  const float* type_emb; /* [1, H]          */
+  const float *emb_ln_g, *emb_ln_b;
+  const SerLayerW* layers;
+} SerXlmrWeights;
+
+/* XLMRobertaModel.forward (eval): embeddings (hf xlm_roberta :75-121, position ids :142-155),
+ * post-LN layers (:421-463).  Replaces ref src/models/text_encoder.py:55.
+ * ids [B,S] int64, attn_mask [B,S] fp32 1/0 -> out [B,S,H] fp32. */
+size_t ser_xlmr_workspace_bytes(const SerXlmrConfig* cfg, int B, int S, int prec);
+int ser_xlmr_forward(const SerXlmrConfig* cfg, const SerXlmrWeights* w, const int64_t* ids,
+                     const float* attn_mask, int B, int S, int prec, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SER_HIP_H */

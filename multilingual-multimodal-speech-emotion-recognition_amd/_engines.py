@@ -1,0 +1,190 @@
+"""Packed-weight engines for the two frozen encoders.
+
+An engine owns the device-resident, kernel-ready form of a HuggingFace state dict (split-bf16
+planes, conv taps in channels-last order, weight-norm folded, Q/K/V fused) plus the C structs that
+`ser_wav2vec2_forward` / `ser_xlmr_forward` take, and a grow-only workspace.  Packing happens once
+per `load_state_dict` (frozen encoders); the forward itself is one C call.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class _Keep:
+    """Holds references to every device tensor whose raw pointer sits in a C struct."""
+
+    def __init__(self):
+        self.t = []
+
+    def f32(self, x, dev):
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        self.t.append(x)
+        return x.data_ptr()
+
+    def split(self, x, dev, want_lo):
+        x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        hi, lo = L.split_bf16(x, want_lo)
+        self.t += [hi, lo]
+        return L.SplitW(hi.data_ptr(), lo.data_ptr() if lo is not None else None)
+
+
+def _pack_layer(keep, sd, names, dev, want_lo):
+    g = lambda k: sd[k]
+    lw = L.LayerW()
+    qkv_w = torch.cat([g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight")], dim=0)
+    qkv_b = torch.cat([g(names["q"] + ".bias"), g(names["k"] + ".bias"), g(names["v"] + ".bias")], dim=0)
+    lw.qkv = keep.split(qkv_w, dev, want_lo)
+    lw.qkv_b = keep.f32(qkv_b, dev)
+    lw.o = keep.split(g(names["o"] + ".weight"), dev, want_lo)
+    lw.o_b = keep.f32(g(names["o"] + ".bias"), dev)
+    lw.ln1_g = keep.f32(g(names["ln1"] + ".weight"), dev)
+    lw.ln1_b = keep.f32(g(names["ln1"] + ".bias"), dev)
+    lw.f1 = keep.split(g(names["f1"] + ".weight"), dev, want_lo)
+    lw.f1_b = keep.f32(g(names["f1"] + ".bias"), dev)
+    lw.f2 = keep.split(g(names["f2"] + ".weight"), dev, want_lo)
+    lw.f2_b = keep.f32(g(names["f2"] + ".bias"), dev)
+    lw.ln2_g = keep.f32(g(names["ln2"] + ".weight"), dev)
+    lw.ln2_b = keep.f32(g(names["ln2"] + ".bias"), dev)
+    return lw
+
+
+_W2V = dict(q="attention.q_proj", k="attention.k_proj", v="attention.v_proj", o="attention.out_proj", ln1="layer_norm",
+            f1="feed_forward.intermediate_dense", f2="feed_forward.output_dense", ln2="final_layer_norm")
+_XLMR = dict(q="attention.self.query", k="attention.self.key", v="attention.self.value", o="attention.output.dense",
+             ln1="attention.output.LayerNorm", f1="intermediate.dense", f2="output.dense", ln2="output.LayerNorm")
+
+
+def _sub(sd, prefix):
+    n = len(prefix)
+    return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+class _Workspace:
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes, dev):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != dev:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return self.buf
+
+
+class Wav2Vec2Engine:
+    """Kernel-ready Wav2Vec2 (hf wav2vec2/modeling_wav2vec2.py Wav2Vec2Model, eval forward)."""
+
+    def __init__(self, hf_config, state_dict, device, prec=L.PREC_BF16X3):
+        c = hf_config
+        assert c.feat_extract_norm == "group" and not c.do_stable_layer_norm and not c.conv_bias, \
+            "only the wav2vec2-base family (group-norm front end, post-LN encoder) is implemented"
+        self.prec = prec
+        self.device = torch.device(device)
+        self.cfg = L.W2vConfig()
+        self.cfg.hidden, self.cfg.layers, self.cfg.heads, self.cfg.ffn = (c.hidden_size, c.num_hidden_layers,
+                                                                           c.num_attention_heads, c.intermediate_size)
+        self.cfg.n_conv = len(c.conv_dim)
+        for i in range(self.cfg.n_conv):
+            self.cfg.conv_dim[i], self.cfg.conv_kernel[i], self.cfg.conv_stride[i] = (c.conv_dim[i], c.conv_kernel[i],
+                                                                                     c.conv_stride[i])
+        self.cfg.pos_kernel, self.cfg.pos_groups = c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups
+        self.cfg.eps = c.layer_norm_eps
+        self.hidden = c.hidden_size
+        self.ws = _Workspace()
+        self.pack(state_dict)
+
+    def pack(self, sd):
+        dev, want_lo = self.device, self.prec == L.PREC_BF16X3
+        keep = _Keep()
+        w = L.W2vWeights()
+        n = self.cfg.n_conv
+        w.conv0_w = keep.f32(sd["feature_extractor.conv_layers.0.conv.weight"].reshape(self.cfg.conv_dim[0], -1), dev)
+        w.gn_g = keep.f32(sd["feature_extractor.conv_layers.0.layer_norm.weight"], dev)
+        w.gn_b = keep.f32(sd["feature_extractor.conv_layers.0.layer_norm.bias"], dev)
+        for i in range(1, n):
+            cw = sd[f"feature_extractor.conv_layers.{i}.conv.weight"]          # [Cout, Cin, k]
+            w.conv_w[i] = keep.split(cw.permute(0, 2, 1).reshape(cw.shape[0], -1), dev, want_lo)   # [Cout, k*Cin]
+        w.fp_ln_g = keep.f32(sd["feature_projection.layer_norm.weight"], dev)
+        w.fp_ln_b = keep.f32(sd["feature_projection.layer_norm.bias"], dev)
+        w.fp_w = keep.split(sd["feature_projection.projection.weight"], dev, want_lo)
+        w.fp_b = keep.f32(sd["feature_projection.projection.bias"], dev)
+        # weight_norm(dim=2) folded once: W = g * v / ||v||_(0,1)   (hf :326-349); frozen => load-time constant
+        g0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original0"].float()
+        v0 = sd["encoder.pos_conv_embed.conv.parametrizations.weight.original1"].float()
+        pw = g0 * v0 / torch.sqrt((v0 * v0).sum(dim=(0, 1), keepdim=True))        # [H, Cg, K]
+        G = self.cfg.pos_groups
+        H, Cg, K = pw.shape
+        pw = pw.reshape(G, H // G, Cg, K).permute(0, 1, 3, 2).reshape(G * (H // G), K * Cg)   # [g][n][j][c]
+        w.pos_w = keep.split(pw, dev, want_lo)
+        w.pos_b = keep.f32(sd["encoder.pos_conv_embed.conv.bias"], dev)
+        w.enc_ln_g = keep.f32(sd["encoder.layer_norm.weight"], dev)
+        w.enc_ln_b = keep.f32(sd["encoder.layer_norm.bias"], dev)
+        self._layers = (L.LayerW * max(1, self.cfg.layers))()
+        for i in range(self.cfg.layers):
+            self._layers[i] = _pack_layer(keep, _sub(sd, f"encoder.layers.{i}."), _W2V, dev, want_lo)
+        w.layers = C.cast(self._layers, C.POINTER(L.LayerW))
+        self.w, self._keep = w, keep
+
+    def out_len(self, T):
+        return L.lib.ser_wav2vec2_out_len(C.byref(self.cfg), int(T))
+
+    def forward(self, wave):
+        """wave [B,T] fp32 raw clips on the device -> last_hidden_state [B,S,H] fp32."""
+        assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2
+        wave = wave.contiguous()
+        B, T = wave.shape
+        S = self.out_len(T)
+        if S <= 0:
+            raise L.SerHipError(f"clip of {T} samples is shorter than the conv receptive field")
+        nbytes = L.lib.ser_wav2vec2_workspace_bytes(C.byref(self.cfg), B, T, self.prec)
+        if nbytes == 0:
+            L.check(-1, "ser_wav2vec2_workspace_bytes")
+        ws = self.ws.get(nbytes, wave.device)
+        out = torch.empty(B, S, self.hidden, dtype=torch.float32, device=wave.device)
+        L.check(L.lib.ser_wav2vec2_forward(C.byref(self.cfg), C.byref(self.w), wave.data_ptr(), B, T, self.prec,
+                                           out.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                "ser_wav2vec2_forward")
+        return out
+
+
+class XlmrEngine:
+    """Kernel-ready XLM-RoBERTa (hf xlm_roberta/modeling_xlm_roberta.py XLMRobertaModel, eval forward)."""
+
+    def __init__(self, hf_config, state_dict, device, prec=L.PREC_BF16X3):
+        c = hf_config
+        self.prec = prec
+        self.device = torch.device(device)
+        self.cfg = L.XlmrConfig(c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size,
+                                c.vocab_size, c.max_position_embeddings, c.pad_token_id, c.layer_norm_eps)
+        self.hidden = c.hidden_size
+        self.ws = _Workspace()
+        self.pack(state_dict)
+
+    def pack(self, sd):
+        dev, want_lo = self.device, self.prec == L.PREC_BF16X3
+        keep = _Keep()
+        w = L.XlmrWeights()
+        w.word_emb = keep.f32(sd["embeddings.word_embeddings.weight"], dev)
+        w.pos_emb = keep.f32(sd["embeddings.position_embeddings.weight"], dev)
+        w.type_emb = keep.f32(sd["embeddings.token_type_embeddings.weight"], dev)
+        w.emb_ln_g = keep.f32(sd["embeddings.LayerNorm.weight"], dev)
+        w.emb_ln_b = keep.f32(sd["embeddings.LayerNorm.bias"], dev)
+        self._layers = (L.LayerW * max(1, self.cfg.layers))()
+        for i in range(self.cfg.layers):
+            self._layers[i] = _pack_layer(keep, _sub(sd, f"encoder.layer.{i}."), _XLMR, dev, want_lo)
+        w.layers = C.cast(self._layers, C.POINTER(L.LayerW))
+        self.w, self._keep = w, keep
+
+    def forward(self, ids, attn_mask):
+        """ids [B,S] int64, attn_mask [B,S] (1/0) on the device -> last_hidden_state [B,S,H] fp32."""
+        assert ids.is_cuda and ids.dtype == torch.int64
+        ids = ids.contiguous()
+        mask = attn_mask.to(torch.float32).contiguous()
+        B, S = ids.shape
+        nbytes = L.lib.ser_xlmr_workspace_bytes(C.byref(self.cfg), B, S, self.prec)
+        ws = self.ws.get(nbytes, ids.device)
+        out = torch.empty(B, S, self.hidden, dtype=torch.float32, device=ids.device)
+        L.check(L.lib.ser_xlmr_forward(C.byref(self.cfg), C.byref(self.w), ids.data_ptr(), mask.data_ptr(), B, S,
+                                       self.prec, out.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+                "ser_xlmr_forward")
+        return out

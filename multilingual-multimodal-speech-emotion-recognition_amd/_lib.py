@@ -1,0 +1,142 @@
+"""ctypes binding of libser_hip.so (the C ABI declared in include/ser_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the shared library is
+missing this module raises at import, and every wrapper raises `SerHipError` on a
+non-zero return code.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libser_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+PREC_BF16, PREC_BF16X3 = 0, 1
+MAX_CONV = 8
+
+
+class SerHipError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        f"(or `make -C {os.path.join(_HERE, 'csrc')}`).  There is no fallback path.")
+lib = C.CDLL(LIB_PATH)
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_size_t
+
+
+class SplitW(C.Structure):
+    _fields_ = [("hi", vp), ("lo", vp)]
+
+
+class LayerW(C.Structure):
+    _fields_ = [("qkv", SplitW), ("qkv_b", vp), ("o", SplitW), ("o_b", vp), ("ln1_g", vp), ("ln1_b", vp),
+                ("f1", SplitW), ("f1_b", vp), ("f2", SplitW), ("f2_b", vp), ("ln2_g", vp), ("ln2_b", vp)]
+
+
+class W2vConfig(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("ffn", i32), ("n_conv", i32),
+                ("conv_dim", i32 * MAX_CONV), ("conv_kernel", i32 * MAX_CONV), ("conv_stride", i32 * MAX_CONV),
+                ("pos_kernel", i32), ("pos_groups", i32), ("eps", f32)]
+
+
+class W2vWeights(C.Structure):
+    _fields_ = [("conv0_w", vp), ("gn_g", vp), ("gn_b", vp), ("conv_w", SplitW * MAX_CONV), ("fp_ln_g", vp),
+                ("fp_ln_b", vp), ("fp_w", SplitW), ("fp_b", vp), ("pos_w", SplitW), ("pos_b", vp), ("enc_ln_g", vp),
+                ("enc_ln_b", vp), ("layers", C.POINTER(LayerW))]
+
+
+class XlmrConfig(C.Structure):
+    _fields_ = [("hidden", i32), ("layers", i32), ("heads", i32), ("ffn", i32), ("vocab", i32), ("max_pos", i32),
+                ("pad_id", i32), ("eps", f32)]
+
+
+class XlmrWeights(C.Structure):
+    _fields_ = [("word_emb", vp), ("pos_emb", vp), ("type_emb", vp), ("emb_ln_g", vp), ("emb_ln_b", vp),
+                ("layers", C.POINTER(LayerW))]
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("ser_last_error_string", C.c_char_p)
+_sig("ser_abi_version", i32)
+_sig("ser_split_bf16", i32, vp, vp, vp, i64, vp)
+_sig("ser_gemm_bf16_nt", i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp)
+_sig("ser_layernorm", i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp)
+_sig("ser_self_attention", i32, vp, vp, vp, i32, i32, i32, vp, vp, vp)
+_sig("ser_wav2vec2_workspace_bytes", sz, C.POINTER(W2vConfig), i32, i32, i32)
+_sig("ser_wav2vec2_out_len", i32, C.POINTER(W2vConfig), i32)
+_sig("ser_wav2vec2_forward", i32, C.POINTER(W2vConfig), C.POINTER(W2vWeights), vp, i32, i32, i32, vp, vp, sz, vp)
+_sig("ser_xlmr_workspace_bytes", sz, C.POINTER(XlmrConfig), i32, i32, i32)
+_sig("ser_xlmr_forward", i32, C.POINTER(XlmrConfig), C.POINTER(XlmrWeights), vp, vp, i32, i32, i32, vp, vp, sz, vp)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.ser_last_error_string()
+        raise SerHipError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "libser_hip needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ---- thin op-level wrappers (used by tests and by weight packing) ---------------------------------
+
+def split_bf16(x, want_lo=True):
+    """fp32 device tensor -> (hi, lo) bf16 planes computed by the library's kernel."""
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    hi = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    lo = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if want_lo else None
+    check(lib.ser_split_bf16(ptr(x), ptr(hi), ptr(lo), x.numel(), stream_ptr()), "ser_split_bf16")
+    return hi, lo
+
+
+def gemm_bf16_nt(a_hi, a_lo, w_hi, w_lo, bias=None, act=ACT_NONE, residual=None, out_f32=True, out_split=False):
+    M, K = a_hi.shape
+    N = w_hi.shape[0]
+    dev = a_hi.device
+    c = torch.empty(M, N, dtype=torch.float32, device=dev) if out_f32 else None
+    ch = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if out_split else None
+    cl = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if out_split and a_lo is not None else None
+    check(lib.ser_gemm_bf16_nt(ptr(a_hi), ptr(a_lo), K, ptr(w_hi), ptr(w_lo), K, M, N, K, ptr(bias), act,
+                               ptr(residual), N, ptr(c), ptr(ch), ptr(cl), N, stream_ptr()), "ser_gemm_bf16_nt")
+    return c, ch, cl
+
+
+def layernorm(x, gamma, beta, eps, x2=None, out_split=False, want_lo=True):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    yh = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device) if out_split else None
+    yl = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device) if out_split and want_lo else None
+    check(lib.ser_layernorm(ptr(x), ptr(x2), ptr(gamma), ptr(beta), eps, rows, D, ptr(y), ptr(yh), ptr(yl),
+                            stream_ptr()), "ser_layernorm")
+    return y, yh, yl
+
+
+def self_attention(qkv_hi, qkv_lo, key_mask, B, S, heads):
+    H = heads * 64
+    ch = torch.empty(B * S, H, dtype=torch.bfloat16, device=qkv_hi.device)
+    cl = torch.empty(B * S, H, dtype=torch.bfloat16, device=qkv_hi.device) if qkv_lo is not None else None
+    check(lib.ser_self_attention(ptr(qkv_hi), ptr(qkv_lo), ptr(key_mask), B, S, heads, ptr(ch), ptr(cl), stream_ptr()),
+          "ser_self_attention")
+    return ch, cl

@@ -1,0 +1,417 @@
+// HBM-bound kernels of the frozen encoders: bf16 splitting, LayerNorm, raw-waveform conv0 +
+// GroupNorm + GELU, positional-conv slab relayout, XLM-R embedding gather + LayerNorm.
+#include <stdarg.h>
+#include "ser_common.h"
+
+static thread_local char g_err[512] = "";
+void ser_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* ser_last_error_string(void) { return g_err; }
+extern "C" int ser_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------
+// fp32 -> split bf16 planes
+// ------------------------------------------------------------------------------------------
+__global__ void split_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                             long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    if (i + 3 < n) {
+      const float4 v = *(const float4*)(x + i);
+      bf16_t h[4], l[4];
+      split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]);
+      split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
+      *(uint2*)(hi + i) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+      if (lo) *(uint2*)(lo + i) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+    } else {
+      for (long long k = i; k < n; ++k) {
+        bf16_t h, l;
+        split_bf16(x[k], h, l);
+        hi[k] = h;
+        if (lo) lo[k] = l;
+      }
+    }
+  }
+}
+
+int ser_launch_split(const float* x, bf16_t* hi, bf16_t* lo, long long n, hipStream_t st) {
+  if (n <= 0) return SER_OK;
+  SER_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)hi % 8 == 0) && (!lo || (uintptr_t)lo % 8 == 0),
+              "split_bf16: pointers must be 16/8-byte aligned");
+  long long blocks = (n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, hi, lo, n);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+extern "C" int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long long n, void* stream) {
+  return ser_launch_split(x, hi, lo, n, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim: one wave per row, row kept in registers (D <= 1024, D % 4 == 0)
+// ------------------------------------------------------------------------------------------
+template <int NV>  // float4 chunks per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, int rows, int D, float* __restrict__ y,
+                                                        bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = D >> 2;
+  const float* xr = x + (long long)row * D;
+  const float* x2r = x2 ? x2 + (long long)row * D : nullptr;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      v[i] = *(const float4*)(xr + c * 4);
+      if (x2r) {
+        const float4 w = *(const float4*)(x2r + c * 4);
+        v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
+      }
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float4 gm = *(const float4*)(gamma + c * 4);
+      const float4 bt = *(const float4*)(beta + c * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+      const long long off = (long long)row * D + c * 4;
+      if (y) *(float4*)(y + off) = o;
+      if (yhi) {
+        bf16_t h[4], l[4];
+        split_bf16(o.x, h[0], l[0]); split_bf16(o.y, h[1], l[1]);
+        split_bf16(o.z, h[2], l[2]); split_bf16(o.w, h[3], l[3]);
+        *(uint2*)(yhi + off) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+        if (ylo) *(uint2*)(ylo + off) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+      }
+    }
+  }
+}
+
+int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows,
+                         int D, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
+  SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d unsupported (need D %% 4 == 0, D <= 1024)", D);
+  if (rows <= 0) return SER_OK;
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  const int nv = ceil_div(D / 4, 64);
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
+  }
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+extern "C" int ser_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps,
+                             int rows, int D, float* y_f32, uint16_t* y_hi, uint16_t* y_lo, void* stream) {
+  return ser_launch_layernorm(x, x2, gamma, beta, eps, rows, D, y_f32, y_hi, y_lo, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// raw waveform statistics: mean and 1/sqrt(var_biased + 1e-7) per clip
+// (hf feature_extraction_wav2vec2.py:78-96)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restrict__ wave, int T,
+                                                          float2* __restrict__ stats) {
+  __shared__ double sh[2][16];
+  const float* x = wave + (long long)blockIdx.x * T;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < T; i += 1024) {
+    const double v = x[i];
+    s += v;
+    q += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = s; sh[1][w] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ss = 0.0, qq = 0.0;
+    for (int i = 0; i < 16; ++i) { ss += sh[0][i]; qq += sh[1][i]; }
+    const double mean = ss / T;
+    double var = qq / T - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[blockIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-7)));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv0 (1 -> C0 channels, kernel KW, stride ST, no bias) + GroupNorm(C0 groups) + GELU
+// (hf modeling_wav2vec2.py:302-323).  Pass 1 accumulates sum / sum-of-squares per (clip, channel)
+// without storing the conv output; pass 2 recomputes the conv (KW MACs), normalises, applies
+// GELU and stores split-bf16 channels-last once.
+// ------------------------------------------------------------------------------------------
+constexpr int C0_FT = 128;   // frames per workgroup
+constexpr int C0_MAXK = 16;
+
+template <bool APPLY>
+__global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wave, const float2* __restrict__ wstats,
+                                                    const float* __restrict__ w, int T, int L0, int C0, int KW, int ST,
+                                                    float2* __restrict__ partial,          // [B][chunks][C0]   (pass 1)
+                                                    const float2* __restrict__ cstats,     // [B][C0] mean,rstd (pass 2)
+                                                    const float* __restrict__ gn_g, const float* __restrict__ gn_b,
+                                                    bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo) {
+  __shared__ float xs[C0_FT * 8 + C0_MAXK];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int t0 = chunk * C0_FT;
+  const int nt = min(C0_FT, L0 - t0);
+  const int nsamp = (nt - 1) * ST + KW;
+  const float2 ws = wstats[b];
+  const float* x = wave + (long long)b * T + (long long)t0 * ST;
+  for (int i = threadIdx.x; i < nsamp; i += 256) xs[i] = (x[i] - ws.x) * ws.y;
+  __syncthreads();
+  for (int cp = threadIdx.x; cp < C0 / 2; cp += 256) {
+    const int c = cp * 2;
+    float w0[C0_MAXK], w1[C0_MAXK];
+#pragma unroll
+    for (int j = 0; j < C0_MAXK; ++j) {
+      w0[j] = j < KW ? w[c * KW + j] : 0.f;
+      w1[j] = j < KW ? w[(c + 1) * KW + j] : 0.f;
+    }
+    if (!APPLY) {
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+      for (int t = 0; t < nt; ++t) {
+        float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < KW) {
+            const float xv = xs[t * ST + j];
+            y0 = fmaf(w0[j], xv, y0);
+            y1 = fmaf(w1[j], xv, y1);
+          }
+        s0 += y0; q0 = fmaf(y0, y0, q0);
+        s1 += y1; q1 = fmaf(y1, y1, q1);
+      }
+      float2* p = partial + ((long long)b * gridDim.x + chunk) * C0 + c;
+      p[0] = make_float2(s0, q0);
+      p[1] = make_float2(s1, q1);
+    } else {
+      const float2 st0 = cstats[(long long)b * C0 + c], st1 = cstats[(long long)b * C0 + c + 1];
+      const float g0 = gn_g[c] * st0.y, g1 = gn_g[c + 1] * st1.y;
+      const float o0 = gn_b[c] - st0.x * g0, o1 = gn_b[c + 1] - st1.x * g1;
+      for (int t = 0; t < nt; ++t) {
+        float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < C0_MAXK; ++j)
+          if (j < KW) {
+            const float xv = xs[t * ST + j];
+            y0 = fmaf(w0[j], xv, y0);
+            y1 = fmaf(w1[j], xv, y1);
+          }
+        const float v0 = gelu_erf(fmaf(y0, g0, o0)), v1 = gelu_erf(fmaf(y1, g1, o1));
+        bf16_t h0, l0, h1, l1;
+        split_bf16(v0, h0, l0);
+        split_bf16(v1, h1, l1);
+        const long long o = ((long long)b * L0 + t0 + t) * C0 + c;
+        *(uint32_t*)(yhi + o) = h0 | ((uint32_t)h1 << 16);
+        if (ylo) *(uint32_t*)(ylo + o) = l0 | ((uint32_t)l1 << 16);
+      }
+    }
+  }
+}
+
+__global__ void conv0_finalize_kernel(const float2* __restrict__ partial, int chunks, int C0, int L0,
+                                      float2* __restrict__ cstats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (c >= C0) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < chunks; ++k) {
+    const float2 p = partial[((long long)b * chunks + k) * C0 + c];
+    s += p.x;
+    q += p.y;
+  }
+  const double mean = s / L0;
+  double var = q / L0 - mean * mean;
+  if (var < 0.0) var = 0.0;
+  cstats[(long long)b * C0 + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+}
+
+size_t ser_conv0_scratch_bytes(int B, int L0, int C0) {
+  const int chunks = ceil_div(L0, C0_FT);
+  return (size_t)B * chunks * C0 * sizeof(float2) + (size_t)B * C0 * sizeof(float2) + (size_t)B * sizeof(float2) + 1024;
+}
+
+int ser_launch_conv0(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0,
+                     int KW, int ST, int L0, bf16_t* yhi, bf16_t* ylo, void* scratch, hipStream_t st) {
+  SER_REQUIRE(KW <= C0_MAXK && ST <= 8 && C0 % 2 == 0, "conv0: unsupported kernel=%d stride=%d channels=%d", KW, ST, C0);
+  SER_REQUIRE(L0 == (T - KW) / ST + 1 && L0 > 0, "conv0: bad output length");
+  const int chunks = ceil_div(L0, C0_FT);
+  char* p = (char*)scratch;
+  float2* wstats = (float2*)p; p += (((size_t)B * sizeof(float2)) + 255) & ~(size_t)255;
+  float2* partial = (float2*)p; p += (size_t)B * chunks * C0 * sizeof(float2);
+  float2* cstats = (float2*)p;
+  hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(1024), 0, st, wave, T, wstats);
+  hipLaunchKernelGGL(conv0_kernel<false>, dim3(chunks, B), dim3(256), 0, st, wave, wstats, w, T, L0, C0, KW, ST, partial,
+                     (const float2*)nullptr, gn_g, gn_b, (bf16_t*)nullptr, (bf16_t*)nullptr);
+  hipLaunchKernelGGL(conv0_finalize_kernel, dim3(ceil_div(C0, 256), B), dim3(256), 0, st, partial, chunks, C0, L0, cstats);
+  hipLaunchKernelGGL(conv0_kernel<true>, dim3(chunks, B), dim3(256), 0, st, wave, wstats, w, T, L0, C0, KW, ST,
+                     (float2*)nullptr, cstats, gn_g, gn_b, yhi, ylo);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// positional-conv slab: z[B,S,H] fp32 -> planes [B][G][S+K-1][Cg] with K/2 zero rows in front
+// (hf modeling_wav2vec2.py:326-368: Conv1d(H,H,K,padding=K/2,groups=G), last frame dropped).
+// With this layout the im2col row of frame t in group g is the contiguous run
+// slab[b][g][t*Cg : t*Cg + K*Cg], i.e. an NT GEMM with lda = Cg.
+// ------------------------------------------------------------------------------------------
+__global__ void posconv_slab_kernel(const float* __restrict__ z, int B, int S, int H, int G, int K,
+                                    bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+  const int Cg = H / G, R = S + K - 1;
+  const long long total = (long long)B * G * R * Cg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cg);
+    long long r1 = i / Cg;
+    const int r = (int)(r1 % R);
+    r1 /= R;
+    const int g = (int)(r1 % G);
+    const int b = (int)(r1 / G);
+    const int t = r - K / 2;
+    float v = 0.f;
+    if (t >= 0 && t < S) v = z[((long long)b * S + t) * H + g * Cg + c];
+    bf16_t h, l;
+    split_bf16(v, h, l);
+    hi[i] = h;
+    if (lo) lo[i] = l;
+  }
+}
+
+int ser_launch_posconv_slab(const float* z, int B, int S, int H, int G, int K, bf16_t* hi, bf16_t* lo, hipStream_t st) {
+  const long long total = (long long)B * (S + K - 1) * H;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(posconv_slab_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, B, S, H, G, K, hi, lo);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// XLM-R embeddings: position ids (cumsum of non-pad, hf xlm_roberta :142-155), then
+// word + type + position gather and LayerNorm (:75-121).  One wave per token.
+// ------------------------------------------------------------------------------------------
+__global__ void xlmr_posid_kernel(const int64_t* __restrict__ ids, int B, int S, int pad_id, int max_pos,
+                                  int* __restrict__ pos) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int run = 0;
+  for (int s = 0; s < S; ++s) {
+    const bool np = ids[(long long)b * S + s] != pad_id;
+    run += np ? 1 : 0;
+    int p = (np ? run : 0) + pad_id;
+    pos[(long long)b * S + s] = p < max_pos ? p : max_pos - 1;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void xlmr_embed_kernel(const int64_t* __restrict__ ids, const int* __restrict__ pos,
+                                                         const float* __restrict__ wemb, const float* __restrict__ pemb,
+                                                         const float* __restrict__ temb, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps, int rows, int D,
+                                                         int vocab, float* __restrict__ y, bf16_t* __restrict__ yhi,
+                                                         bf16_t* __restrict__ ylo) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  long long id = ids[row];
+  if (id < 0) id = 0;
+  if (id >= vocab) id = vocab - 1;
+  const float* wr = wemb + id * D;
+  const float* pr = pemb + (long long)pos[row] * D;
+  const int nchunk = D >> 2;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float4 a = *(const float4*)(wr + c * 4), t = *(const float4*)(temb + c * 4), p = *(const float4*)(pr + c * 4);
+      v[i].x = (a.x + t.x) + p.x; v[i].y = (a.y + t.y) + p.y; v[i].z = (a.z + t.z) + p.z; v[i].w = (a.w + t.w) + p.w;
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      const float4 gm = *(const float4*)(gamma + c * 4), bt = *(const float4*)(beta + c * 4);
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+      const long long off = (long long)row * D + c * 4;
+      *(float4*)(y + off) = o;
+      bf16_t h[4], l[4];
+      split_bf16(o.x, h[0], l[0]); split_bf16(o.y, h[1], l[1]);
+      split_bf16(o.z, h[2], l[2]); split_bf16(o.w, h[3], l[3]);
+      *(uint2*)(yhi + off) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+      if (ylo) *(uint2*)(ylo + off) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+    }
+  }
+}
+
+int ser_launch_xlmr_embed(const int64_t* ids, int B, int S, const float* wemb, const float* pemb, const float* temb,
+                          const float* gamma, const float* beta, float eps, int D, int vocab, int max_pos, int pad_id,
+                          int* pos_scratch, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
+  SER_REQUIRE(D % 4 == 0 && D <= 1024, "xlmr_embed: D=%d unsupported", D);
+  hipLaunchKernelGGL(xlmr_posid_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, ids, B, S, pad_id, max_pos, pos_scratch);
+  const int rows = B * S;
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  const int nv = ceil_div(D / 4, 64);
+#define EMB(NVV) hipLaunchKernelGGL(xlmr_embed_kernel<NVV>, grid, block, 0, st, ids, pos_scratch, wemb, pemb, temb, gamma, beta, eps, rows, D, vocab, y, yhi, ylo)
+  switch (nv) { case 1: EMB(1); break; case 2: EMB(2); break; case 3: EMB(3); break; default: EMB(4); break; }
+#undef EMB
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}

@@ -1,0 +1,206 @@
+// Split-bf16 NT GEMM for the frozen encoders (gfx950 / CDNA4).
+//
+//   C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual        fp32 accumulate on MFMA
+//
+// Operands are bf16 planes with K contiguous.  In parity mode (both hi and lo planes present)
+// every product is  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo  (three v_mfma_f32_16x16x32_bf16), which
+// carries ~2^-16 relative error per product instead of bf16's 2^-8; in fast mode only the hi
+// planes are read.
+//
+// Structure: BMxBN output tile per 256-thread workgroup (4 waves as 2x2), BK = 64.
+// Global -> LDS goes through global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): one wave
+// instruction moves 8 rows x 128 B.  The LDS image is lane-linear, so the bank-conflict swizzle
+// (16-byte chunk index XOR row&7) is applied to the per-lane SOURCE address and again on the
+// ds_read_b128 side (cdna_hip_programming.md rule 21).  Two LDS stages: the loads of k-tile t+1
+// are in flight while tile t is multiplied; one barrier per k-tile.
+#include "ser_common.h"
+
+namespace {
+
+constexpr int BK = 64;           // bf16 elements per k-tile = 128 B per row
+constexpr int ROW_BYTES = 128;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Stage R rows x 64 bf16 of a K-contiguous matrix into a swizzled LDS tile.
+// rows beyond `rmax` are clamped (their products are discarded by the epilogue).
+template <int R>
+SER_DEVFN void stage_tile(const bf16_t* __restrict__ base, long long ld, int row0, int rmax, int k0,
+                          char* lds_tile, int wave, int lane) {
+  const int r = lane >> 3;
+  const int c = (lane & 7) ^ r;   // source chunk for LDS chunk position lane&7 of row r
+#pragma unroll
+  for (int p = wave; p < R / 8; p += 4) {
+    int row = row0 + p * 8 + r;
+    row = row < rmax ? row : rmax;
+    const bf16_t* src = base + (long long)row * ld + k0 + c * 8;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + p * 1024), 16, 0, 0);
+  }
+}
+
+// 16-byte fragment of row `row` (tile-local), 16-B chunk `chunk` (0..7)
+SER_DEVFN bf16x8 lds_frag(const char* tile, int row, int chunk) {
+  const int off = (row >> 3) * 1024 + (row & 7) * ROW_BYTES + ((chunk ^ (row & 7)) << 4);
+  return *(const bf16x8*)(tile + off);
+}
+
+SER_DEVFN float apply_act(float v, int act) {
+  if (act == SER_ACT_GELU) return gelu_erf(v);
+  if (act == SER_ACT_RELU) return fmaxf(v, 0.0f);
+  return v;
+}
+
+template <int BM, int BN, bool X3>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) {
+  constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
+  constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
+  constexpr int STAGE = (A_TILE + W_TILE) * NPL;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
+
+  const long long aoff = b1 * g.sa1 + b2 * g.sa2, woff = b1 * g.sw1 + b2 * g.sw2;
+  const bf16_t* a_hi = g.a_hi + aoff;
+  const bf16_t* w_hi = g.w_hi + woff;
+  const bf16_t* a_lo = X3 ? g.a_lo + aoff : nullptr;
+  const bf16_t* w_lo = X3 ? g.w_lo + woff : nullptr;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / BK;
+  auto stage = [&](int kt, int buf) {
+    char* s = lds + buf * STAGE;
+    stage_tile<BM>(a_hi, g.lda, m0, g.M - 1, kt * BK, s, wave, lane);
+    stage_tile<BN>(w_hi, g.ldw, n0, g.N - 1, kt * BK, s + A_TILE * NPL, wave, lane);
+    if (X3) {
+      stage_tile<BM>(a_lo, g.lda, m0, g.M - 1, kt * BK, s + A_TILE, wave, lane);
+      stage_tile<BN>(w_lo, g.ldw, n0, g.N - 1, kt * BK, s + A_TILE * NPL + W_TILE, wave, lane);
+    }
+  };
+
+  stage(0, 0);
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders it for every wave
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char* s = lds + (kt & 1) * STAGE;
+    const char* sa = s + wm * WM * ROW_BYTES;
+    const char* sw = s + A_TILE * NPL + wn * WN * ROW_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = lds_frag(sa, i * 16 + fr, ks * 4 + fq);
+        if (X3) al[i] = lds_frag(sa + A_TILE, i * 16 + fr, ks * 4 + fq);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = lds_frag(sw, j * 16 + fr, ks * 4 + fq);
+        if (X3) bl[j] = lds_frag(sw + W_TILE, j * 16 + fr, ks * 4 + fq);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+
+  // epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  const long long coff = b1 * g.sc1 + b2 * g.sc2;
+  const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
+  const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + fr;
+    if (n >= g.N) continue;
+    const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * WM + i * 16 + fq * 4 + r;
+        if (m >= g.M) continue;
+        float v = apply_act(acc[i][j][r] + bv, g.act);
+        if (res) v += res[(long long)m * g.ldr + n];
+        const long long o = coff + (long long)m * g.ldc + n;
+        if (g.c_f32) g.c_f32[o] = v;
+        if (g.c_hi) {
+          bf16_t h, l;
+          split_bf16(v, h, l);
+          g.c_hi[o] = h;
+          if (g.c_lo) g.c_lo[o] = l;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
+  const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+  dim3 grid(tiles, 1, g.nb1 * g.nb2), block(256);
+  if (g.a_lo && g.w_lo)
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, 0, st, g);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+}  // namespace
+
+int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st) {
+  SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+  SER_REQUIRE(g.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", g.K, BK);
+  SER_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm_bf16: lda=%d ldw=%d must be multiples of 8", g.lda, g.ldw);
+  SER_REQUIRE(g.a_hi && g.w_hi, "gemm_bf16: null operand");
+  SER_REQUIRE((g.a_lo == nullptr) == (g.w_lo == nullptr) || true, "unreachable");
+  SER_REQUIRE(g.nb1 >= 1 && g.nb2 >= 1, "gemm_bf16: bad batch");
+  // tile choice: fill >= 256 CUs when the problem allows it
+  const long long nb = (long long)g.nb1 * g.nb2;
+  const long long t128 = (long long)ceil_div(g.M, 128) * ceil_div(g.N, 128) * nb;
+  if (g.N <= 64) return launch_cfg<128, 64>(g, st);
+  if (t128 >= 384 || g.M <= 64) {
+    if (g.M <= 64) return launch_cfg<64, 128>(g, st);
+    return launch_cfg<128, 128>(g, st);
+  }
+  const long long t64 = (long long)ceil_div(g.M, 64) * ceil_div(g.N, 128) * nb;
+  if (t64 >= 256) return launch_cfg<64, 128>(g, st);
+  return launch_cfg<64, 64>(g, st);
+}
+
+extern "C" int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi,
+                                const uint16_t* w_lo, int ldw, int M, int N, int K, const float* bias, int act,
+                                const float* residual, int ldr, float* c_f32, uint16_t* c_hi, uint16_t* c_lo,
+                                int ldc, void* stream) {
+  SerGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = a_hi; g.a_lo = a_lo; g.w_hi = w_hi; g.w_lo = w_lo;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw;
+  g.nb1 = 1; g.nb2 = 1;
+  g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
+  g.c_f32 = c_f32; g.c_hi = c_hi; g.c_lo = c_lo; g.ldc = ldc;
+  if ((a_lo == nullptr) != (w_lo == nullptr)) { g.a_lo = nullptr; g.w_lo = nullptr; }
+  return ser_launch_gemm_bf16(g, (hipStream_t)stream);
+}

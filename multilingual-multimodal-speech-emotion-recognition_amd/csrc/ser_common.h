@@ -1,0 +1,121 @@
+// Internal helpers shared by the HIP translation units of libser_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/ser_hip.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SER_DEVFN __device__ __forceinline__
+
+// thread-local error text, returned by ser_last_error_string()
+void ser_set_error(const char* fmt, ...);
+
+#define SER_CHECK_HIP(expr)                                                         \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess) {                                                         \
+      ser_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return SER_E_HIP;                                                             \
+    }                                                                               \
+  } while (0)
+
+#define SER_REQUIRE(cond, ...)                       \
+  do {                                               \
+    if (!(cond)) {                                   \
+      ser_set_error(__VA_ARGS__);                    \
+      return SER_E_ARG;                              \
+    }                                                \
+  } while (0)
+
+#define SER_LAUNCH_CHECK()                                              \
+  do {                                                                  \
+    hipError_t _e = hipGetLastError();                                  \
+    if (_e != hipSuccess) {                                             \
+      ser_set_error("%s:%d: launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      return SER_E_HIP;                                                 \
+    }                                                                   \
+  } while (0)
+
+#define SER_TRY(expr)            \
+  do {                           \
+    int _rc = (expr);            \
+    if (_rc != SER_OK) return _rc; \
+  } while (0)
+
+// round-to-nearest-even fp32 -> bf16 (NaN kept quiet)
+SER_DEVFN bf16_t f2bf(float x) {
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+SER_DEVFN float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// x = hi + lo (+ O(2^-17 |x|)); both bf16
+SER_DEVFN void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+  hi = f2bf(x);
+  lo = f2bf(x - bf2f(hi));
+}
+
+SER_DEVFN float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+SER_DEVFN float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+SER_DEVFN float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// simple bump allocator over a caller-provided workspace
+struct SerArena {
+  char* base;
+  size_t cap, off;
+  SerArena(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+  void* take(size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    if (base != nullptr && a + bytes > cap) return nullptr;
+    off = a + bytes;
+    return base ? base + a : (void*)1;
+  }
+  template <typename T> T* get(size_t n) { return (T*)take(n * sizeof(T)); }
+};
+
+// ---- internal launchers (defined across the .hip files) -------------------------------------
+struct SerGemmArgs {
+  const bf16_t *a_hi, *a_lo;   // [M, lda] K-contiguous rows (lo may be null -> single bf16 product)
+  const bf16_t *w_hi, *w_lo;   // [N, ldw] K-contiguous rows
+  int M, N, K, lda, ldw;
+  int nb1, nb2;                // two batch dims (grid.z = nb1*nb2)
+  long long sa1, sa2, sw1, sw2, sc1, sc2, sr1, sr2, sbias1, sbias2;  // element strides per batch dim
+  const float* bias;           // [N] or null
+  int act;                     // SER_ACT_*
+  const float* residual;       // [M, ldr] added after activation, or null
+  int ldr;
+  float* c_f32;                // [M, ldc] or null
+  bf16_t *c_hi, *c_lo;         // [M, ldc] planes or null
+  int ldc;
+};
+int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st);
+int ser_launch_split(const float* x, bf16_t* hi, bf16_t* lo, long long n, hipStream_t st);
+int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows,
+                         int D, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st);
+size_t ser_conv0_scratch_bytes(int B, int L0, int C0);
+int ser_launch_conv0(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0,
+                     int KW, int ST, int L0, bf16_t* yhi, bf16_t* ylo, void* scratch, hipStream_t st);
+int ser_launch_posconv_slab(const float* z, int B, int S, int H, int G, int K, bf16_t* hi, bf16_t* lo, hipStream_t st);
+int ser_launch_xlmr_embed(const int64_t* ids, int B, int S, const float* wemb, const float* pemb, const float* temb,
+                          const float* gamma, const float* beta, float eps, int D, int vocab, int max_pos, int pad_id,
+                          int* pos_scratch, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st);
+int ser_launch_self_attention(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const float* key_mask, int B, int S,
+                              int heads, bf16_t* ctx_hi, bf16_t* ctx_lo, hipStream_t st);

@@ -1,0 +1,99 @@
+"""GPU parity tests for the op-level C-ABI entry points (run with -m gpu on an MI355X).
+Every comparison is against a plain fp32/fp64 torch-CPU restatement of the same op."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import ser_amd  # noqa: F401
+    import ser_amd._lib as lib
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return lib
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_split_bf16_reconstructs(L):
+    x = _rand(1000, 37, seed=1).cuda()
+    hi, lo = L.split_bf16(x)
+    rec = hi.float() + lo.float()
+    assert float((rec - x).abs().max() / x.abs().max()) < 2 ** -15
+    assert torch.equal(hi, x.to(torch.bfloat16))      # round-to-nearest-even, same as torch
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (199, 768, 768), (3184, 2304, 768), (37, 48, 512), (1, 64, 64),
+                                   (300, 3072, 768), (257, 130, 192)])
+@pytest.mark.parametrize("x3", [True, False])
+def test_gemm_bf16_nt(L, M, N, K, x3):
+    a, w = _rand(M, K, seed=2), _rand(N, K, seed=3) / np.sqrt(K)
+    bias, res = _rand(N, seed=4), _rand(M, N, seed=5)
+    ah, al = L.split_bf16(a.cuda(), x3)
+    wh, wl = L.split_bf16(w.cuda(), x3)
+    c, ch, cl = L.gemm_bf16_nt(ah, al, wh, wl, bias.cuda(), L.ACT_GELU, res.cuda(), out_f32=True, out_split=True)
+    torch.cuda.synchronize()
+    if x3:
+        ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+        tol = 3e-5
+    else:   # fast mode: compare with the bf16-rounded operands multiplied exactly
+        ref = torch.nn.functional.gelu(ah.cpu().double() @ wh.cpu().double().t() + bias.double()) + res.double()
+        tol = 2e-5
+    err = (c.cpu().double() - ref).abs().max().item()
+    assert err < tol, f"max abs err {err}"
+    rec = ch.float() + (cl.float() if cl is not None else 0)
+    assert (rec.cpu() - c.cpu()).abs().max().item() < (1e-4 if x3 else 4e-2)
+
+
+def test_gemm_strided_rows_is_conv(L):
+    """Conv1d(k=3, stride=2) over channels-last activations as an NT GEMM with lda = stride*C."""
+    C_, Lin, Cout, k, s = 64, 41, 64, 3, 2
+    x = _rand(Lin, C_, seed=6)
+    w = _rand(Cout, C_, k, seed=7) / np.sqrt(C_ * k)
+    Lout = (Lin - k) // s + 1
+    xh, xl = L.split_bf16(x.cuda())
+    wp = w.permute(0, 2, 1).reshape(Cout, k * C_).contiguous()
+    wh, wl = L.split_bf16(wp.cuda())
+    c = torch.empty(Lout, Cout, device="cuda")
+    L.check(L.lib.ser_gemm_bf16_nt(L.ptr(xh), L.ptr(xl), s * C_, L.ptr(wh), L.ptr(wl), k * C_, Lout, Cout, k * C_, None,
+                                   L.ACT_NONE, None, 0, L.ptr(c), None, None, Cout, L.stream_ptr()))
+    ref = torch.nn.functional.conv1d(x.t()[None].double(), w.double(), stride=s)[0].t()
+    assert (c.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("D", [64, 128, 512, 768, 1024])
+def test_layernorm(L, D):
+    x, x2 = _rand(77, D, seed=8, scale=3.0), _rand(77, D, seed=9)
+    g, b = _rand(D, seed=10), _rand(D, seed=11)
+    y, yh, yl = L.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-5, x2=x2.cuda(), out_split=True)
+    ref = torch.nn.functional.layer_norm((x + x2).double(), (D,), g.double(), b.double(), 1e-5)
+    assert (y.cpu().double() - ref).abs().max().item() < 5e-6
+    assert ((yh.float() + yl.float()).cpu() - y.cpu()).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("B,S,heads,masked", [(2, 199, 12, False), (3, 32, 12, True), (1, 7, 2, True), (2, 130, 2, False)])
+@pytest.mark.parametrize("x3", [True, False])
+def test_self_attention(L, B, S, heads, masked, x3):
+    H = heads * 64
+    qkv = _rand(B * S, 3 * H, seed=12)
+    mask = torch.ones(B, S)
+    if masked:
+        for b in range(B):
+            mask[b, max(1, S - 1 - 2 * b):] = 0
+    qh, ql = L.split_bf16(qkv.cuda(), x3)
+    ch, cl = L.self_attention(qh, ql, mask.cuda() if masked else None, B, S, heads)
+    got = ch.float().cpu() + (cl.float().cpu() if cl is not None else 0)
+    src = qkv.double() if x3 else qh.float().cpu().double()
+    q, k, v = (src[:, i * H:(i + 1) * H].reshape(B, S, heads, 64).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(2, 3) / 8.0
+    s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H)
+    err = (got.double() - ref).abs().max().item()
+    assert err < (5e-5 if x3 else 2e-2), f"max abs err {err}"
