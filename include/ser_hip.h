@@ -146,6 +146,73 @@ int ser_xlmr_forward(const SerXlmrConfig* cfg, const SerXlmrWeights* w, const in
                      const float* attn_mask, int B, int S, int prec, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * trainable head, fp32 (forward and backward)
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[M,N] (+)= act(A.B + bias) + residual with A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn],
+ * exact fp32 on v_mfma_f32_16x16x4_f32.  One kernel serves y = x W^T, dx = dy W and dW += dy^T x of
+ * every torch.nn.Linear in ref src/models/{audio_encoder.py:19-21, cross_attention.py:15-26,
+ * pooling.py:9-13, fusion.py:8-16, classifier.py:77-129,190-197}. */
+int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, long long sbk,
+                 long long sbn, int M, int N, int K, const float* bias, int act, const float* residual,
+                 int ldr, float* c, int ldc, int accumulate, void* stream);
+
+/* nn.LayerNorm forward keeping z = x (+ x2), mean, rstd for backward (cross_attention.py:28-29,
+ * classifier.py:79,107,118,125); backward gives dx (+ dx_add) and dgamma/dbeta. */
+int ser_layernorm_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float eps,
+                      int rows, int D, float* y, float* z, float* mean, float* rstd, void* stream);
+int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
+                      float* dbeta, int accumulate_params, void* stream);
+
+int ser_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
+int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream);
+int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);
+int ser_axpby(const float* x, float a, float b, long long n, float* y, void* stream); /* y = a x + b y */
+
+/* softmax(q k^T / sqrt(hd) + key mask) v of nn.MultiheadAttention (cross_attention.py:41,49;
+ * torch nn/functional.py multi_head_attention_forward).  P [B,heads,Sq,Sk] is kept for backward. */
+int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                  const float* key_mask, int B, int Sq, int Sk, int heads, int head_dim, float* P,
+                  float* ctx, int ldc, void* stream);
+int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk,
+                  const float* v, int ldv, const float* P, int B, int Sq, int Sk, int heads, int head_dim,
+                  float* dS, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, void* stream);
+
+/* AttentiveStatsPooling core (pooling.py:21-28): masked softmax over time of `logits`, weighted
+ * mean and std -> out [B,2D]; alpha [B,S] kept for backward. */
+int ser_pool_fwd(const float* x, const float* logits, const float* mask, int B, int S, int D,
+                 float* alpha, float* out, void* stream);
+int ser_pool_bwd(const float* dout, const float* x, const float* alpha, const float* out, int B, int S,
+                 int D, float* dx, float* dalpha_scratch, float* dlogits, void* stream);
+
+/* FusionLayer mix (fusion.py:21-25) from the two gate logits ga, gt [B]. */
+int ser_fusion_mix_fwd(const float* a, const float* t, const float* ga, const float* gt, int B, int P,
+                       float* out, void* stream);
+int ser_fusion_mix_bwd(const float* dout, const float* a, const float* t, const float* ga, const float* gt,
+                       int B, int P, float* da, float* dt, float* dga, float* dgt, void* stream);
+
+/* The training loss of train.py:154-168 (label-smoothed CE + w_focal * class-balanced focal +
+ * w_unc * uncertainty term + w_proto * prototype loss) and its gradients in one launch.
+ * losses[5] = {total, ce, focal, unc, proto}.  grad_scale: device scalar (NULL = 1). */
+int ser_train_loss(const float* logits, const float* unc, const float* fused, const float* protos,
+                   const int64_t* labels, int B, int C, int D, float smoothing, float cb_beta, float gamma,
+                   float w_focal, float w_unc, float w_proto, float margin, int use_proto,
+                   const float* grad_scale, float* losses, float* dlogits, float* dunc, float* dfused,
+                   float* dprotos, void* stream);
+
+/* OpenMax rescale of eval logits (classifier.py:240-275), in place. */
+int ser_openmax(const float* feats, const float* act_vec, const float* walpha, const float* wbeta,
+                const float* wtau, int B, int C, int F, float thresh, float reduce, float* logits,
+                void* stream);
+
+/* torch.optim.AdamW update of a flat fp32 segment (train.py:72-83,169-177).
+ * hyper (device) = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; effective lr = hyper[0] * lr_mult. */
+int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float lr_mult,
+              float weight_decay, float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

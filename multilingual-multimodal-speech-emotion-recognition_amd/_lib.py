@@ -140,3 +140,21 @@ def self_attention(qkv_hi, qkv_lo, key_mask, B, S, heads):
     check(lib.ser_self_attention(ptr(qkv_hi), ptr(qkv_lo), ptr(key_mask), B, S, heads, ptr(ch), ptr(cl), stream_ptr()),
           "ser_self_attention")
     return ch, cl
+
+# ---- trainable head (fp32) -------------------------------------------------------------------------
+_sig("ser_gemm_f32", i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp)
+_sig("ser_layernorm_fwd", i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp)
+_sig("ser_layernorm_bwd", i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp)
+_sig("ser_colsum", i32, vp, i32, i32, i32, vp, i32, vp)
+_sig("ser_act_fwd", i32, vp, i32, i64, vp, vp)
+_sig("ser_act_bwd", i32, vp, vp, i32, i64, vp, vp)
+_sig("ser_axpby", i32, vp, f32, f32, i64, vp, vp)
+_sig("ser_xattn_fwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp)
+_sig("ser_xattn_bwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp)
+_sig("ser_pool_fwd", i32, vp, vp, vp, i32, i32, i32, vp, vp, vp)
+_sig("ser_pool_bwd", i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp)
+_sig("ser_fusion_mix_fwd", i32, vp, vp, vp, vp, i32, i32, vp, vp)
+_sig("ser_fusion_mix_bwd", i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp)
+_sig("ser_train_loss", i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp)
+_sig("ser_openmax", i32, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp)
+_sig("ser_adamw", i32, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, vp)

@@ -1,0 +1,169 @@
+"""fp32 head operators: thin Python wrappers that allocate outputs (torch = device memory only)
+and launch the HIP kernels of libser_hip.so.  No arithmetic happens in torch here."""
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = L.ACT_NONE, L.ACT_GELU, L.ACT_RELU, L.ACT_TANH, L.ACT_SIGMOID
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def empty(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def linear_fwd(x, W, b=None, act=ACT_NONE, residual=None, out=None):
+    """y[M,N] = act(x[M,K] W[N,K]^T + b) + residual."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = out if out is not None else empty(M, N, like=x)
+    L.check(L.lib.ser_gemm_f32(L.ptr(x), K, 1, L.ptr(W), 1, K, M, N, K, L.ptr(b), act, L.ptr(residual), N, L.ptr(y), N, 0,
+                               L.stream_ptr()), "ser_gemm_f32(fwd)")
+    return y
+
+
+def linear_dgrad(dy, W, out=None, accumulate=False):
+    """dx[M,K] (+)= dy[M,N] W[N,K]."""
+    M, N = dy.shape
+    K = W.shape[1]
+    dx = out if out is not None else empty(M, K, like=dy)
+    L.check(L.lib.ser_gemm_f32(L.ptr(dy), N, 1, L.ptr(W), K, 1, M, K, N, None, ACT_NONE, None, 0, L.ptr(dx), K,
+                               1 if accumulate else 0, L.stream_ptr()), "ser_gemm_f32(dgrad)")
+    return dx
+
+
+def linear_wgrad(dy, x, dW, db=None, accumulate=False):
+    """dW[N,K] (+)= dy[M,N]^T x[M,K];  db[N] (+)= colsum(dy)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    acc = 1 if accumulate else 0
+    L.check(L.lib.ser_gemm_f32(L.ptr(dy), 1, N, L.ptr(x), K, 1, N, K, M, None, ACT_NONE, None, 0, L.ptr(dW), K, acc,
+                               L.stream_ptr()), "ser_gemm_f32(wgrad)")
+    if db is not None:
+        L.check(L.lib.ser_colsum(L.ptr(dy), M, N, N, L.ptr(db), acc, L.stream_ptr()), "ser_colsum")
+
+
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    L.check(L.lib.ser_act_fwd(L.ptr(x), act, x.numel(), L.ptr(y), L.stream_ptr()), "ser_act_fwd")
+    return y
+
+
+def act_bwd(dy, y, act, inplace=True):
+    dx = dy if inplace else torch.empty_like(dy)
+    L.check(L.lib.ser_act_bwd(L.ptr(dy), L.ptr(y), act, dy.numel(), L.ptr(dx), L.stream_ptr()), "ser_act_bwd")
+    return dx
+
+
+def axpby(x, y, a=1.0, b=1.0):
+    """y = a*x + b*y in place."""
+    L.check(L.lib.ser_axpby(L.ptr(x), a, b, x.numel(), L.ptr(y), L.stream_ptr()), "ser_axpby")
+    return y
+
+
+def ln_fwd(x, gamma, beta, eps=1e-5, x2=None, keep_z=None):
+    """-> y, saved=(z, mean, rstd).  z is x itself unless a second addend is given."""
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    need_z = x2 is not None if keep_z is None else keep_z
+    z = torch.empty_like(x) if need_z else None
+    mean, rstd = empty(rows, like=x), empty(rows, like=x)
+    L.check(L.lib.ser_layernorm_fwd(L.ptr(x), L.ptr(x2), L.ptr(gamma), L.ptr(beta), eps, rows, D, L.ptr(y), L.ptr(z),
+                                    L.ptr(mean), L.ptr(rstd), L.stream_ptr()), "ser_layernorm_fwd")
+    return y, (z if need_z else x, mean, rstd)
+
+
+def ln_bwd(dy, saved, gamma, dgamma=None, dbeta=None, accumulate=False, dx_add=None, need_dx=True):
+    z, mean, rstd = saved
+    rows, D = dy.shape
+    dx = torch.empty_like(dy) if need_dx else None
+    L.check(L.lib.ser_layernorm_bwd(L.ptr(dy), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dx_add), rows, D,
+                                    L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, L.stream_ptr()),
+            "ser_layernorm_bwd")
+    return dx
+
+
+def xattn_fwd(q, k, v, key_mask, B, Sq, Sk, heads):
+    """q [B*Sq,E], k,v [B*Sk,E] (may be column slices given as (tensor, ld) through .stride) -> ctx, P."""
+    E = q.shape[1]
+    hd = E // heads
+    P = empty(B, heads, Sq, Sk, like=q)
+    ctx = empty(B * Sq, E, like=q)
+    L.check(L.lib.ser_xattn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                L.ptr(key_mask), B, Sq, Sk, heads, hd, L.ptr(P), L.ptr(ctx), E, L.stream_ptr()),
+            "ser_xattn_fwd")
+    return ctx, P
+
+
+def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads):
+    E = q.shape[1]
+    hd = E // heads
+    dS = torch.empty_like(P)
+    dq, dk, dv = empty(B * Sq, E, like=q), empty(B * Sk, E, like=q), empty(B * Sk, E, like=q)
+    L.check(L.lib.ser_xattn_bwd(L.ptr(dctx), E, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
+                                v.stride(0), L.ptr(P), B, Sq, Sk, heads, hd, L.ptr(dS), L.ptr(dq), E, L.ptr(dk), E, L.ptr(dv),
+                                E, L.stream_ptr()), "ser_xattn_bwd")
+    return dq, dk, dv
+
+
+def pool_fwd(x, logits, mask):
+    B, S, D = x.shape
+    alpha, out = empty(B, S, like=x), empty(B, 2 * D, like=x)
+    L.check(L.lib.ser_pool_fwd(L.ptr(x), L.ptr(logits), L.ptr(mask), B, S, D, L.ptr(alpha), L.ptr(out), L.stream_ptr()),
+            "ser_pool_fwd")
+    return out, alpha
+
+
+def pool_bwd(dout, x, alpha, out):
+    B, S, D = x.shape
+    dx, scratch, dlogits = torch.empty_like(x), empty(B, S, like=x), empty(B, S, like=x)
+    L.check(L.lib.ser_pool_bwd(L.ptr(dout), L.ptr(x), L.ptr(alpha), L.ptr(out), B, S, D, L.ptr(dx), L.ptr(scratch),
+                               L.ptr(dlogits), L.stream_ptr()), "ser_pool_bwd")
+    return dx, dlogits
+
+
+def fusion_mix_fwd(a, t, ga, gt):
+    B, P = a.shape
+    out = torch.empty_like(a)
+    L.check(L.lib.ser_fusion_mix_fwd(L.ptr(a), L.ptr(t), L.ptr(ga), L.ptr(gt), B, P, L.ptr(out), L.stream_ptr()),
+            "ser_fusion_mix_fwd")
+    return out
+
+
+def fusion_mix_bwd(dout, a, t, ga, gt):
+    B, P = a.shape
+    da, dt = torch.empty_like(a), torch.empty_like(t)
+    dga, dgt = empty(B, 1, like=a), empty(B, 1, like=a)
+    L.check(L.lib.ser_fusion_mix_bwd(L.ptr(dout), L.ptr(a), L.ptr(t), L.ptr(ga), L.ptr(gt), B, P, L.ptr(da), L.ptr(dt),
+                                     L.ptr(dga), L.ptr(dgt), L.stream_ptr()), "ser_fusion_mix_bwd")
+    return da, dt, dga, dgt
+
+
+def train_loss(logits, unc, fused, protos, labels, smoothing=0.1, cb_beta=0.9999, gamma=2.0, w_focal=0.3, w_unc=0.05,
+               w_proto=0.01, margin=0.5, use_proto=True, grad_scale=None):
+    B, C = logits.shape
+    D = fused.shape[1]
+    losses = empty(5, like=logits)
+    dlogits, dunc = torch.empty_like(logits), torch.empty_like(unc)
+    dfused, dprotos = torch.empty_like(fused), torch.empty_like(protos)
+    L.check(L.lib.ser_train_loss(L.ptr(logits), L.ptr(unc), L.ptr(fused), L.ptr(protos), L.ptr(labels), B, C, D, smoothing,
+                                 cb_beta, gamma, w_focal, w_unc, w_proto, margin, 1 if use_proto else 0,
+                                 L.ptr(grad_scale), L.ptr(losses), L.ptr(dlogits), L.ptr(dunc), L.ptr(dfused),
+                                 L.ptr(dprotos), L.stream_ptr()), "ser_train_loss")
+    return losses, dlogits, dunc, dfused, dprotos
+
+
+def openmax_(feats, act_vec, walpha, wbeta, wtau, logits, thresh=0.3, reduce=0.8):
+    B, F = feats.shape
+    C = logits.shape[1]
+    L.check(L.lib.ser_openmax(L.ptr(feats), L.ptr(act_vec), L.ptr(walpha), L.ptr(wbeta), L.ptr(wtau), B, C, F, thresh,
+                              reduce, L.ptr(logits), L.stream_ptr()), "ser_openmax")
+    return logits
+
+
+def adamw_(p, g, m, v, hyper, lr_mult, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8):
+    L.check(L.lib.ser_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper), lr_mult, weight_decay, beta1,
+                            beta2, eps, L.stream_ptr()), "ser_adamw")

@@ -1,0 +1,66 @@
+"""Flat parameter / gradient storage for the trainable head modules.
+
+Each module keeps its grad-bearing parameters as views into ONE contiguous fp32 buffer, with a
+matching flat gradient buffer.  That gives (a) one RCCL all-reduce per module bucket instead of one
+per tensor, (b) one fused AdamW launch per optimizer group, and (c) gradient kernels that write
+straight into the bucket (no autograd-side copies).  `state_dict()` / `load_state_dict()` are
+unaffected because the nn.Parameters stay in place (their `.data` is re-pointed at the views).
+"""
+import torch
+
+ALIGN = 64  # floats (256 B): keeps every view aligned for float4 kernels
+
+
+class FlatParams:
+    def __init__(self, params):
+        self.params = [p for p in params]
+        self.flat = None
+        self.gflat = None
+        self.offsets = []
+        off = 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+
+    def _views(self, buf):
+        return [buf[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+
+    def ensure(self):
+        """(Re)flatten when the parameters are not (or no longer) views of the flat buffer."""
+        if not self.params:
+            return self
+        dev = self.params[0].device
+        ok = self.flat is not None and self.flat.device == dev
+        if ok:
+            base = self.flat.data_ptr()
+            ok = all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
+        if not ok:
+            flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+            for v, p in zip(self._views(flat), self.params):
+                v.copy_(p.data)
+                p.data = v
+            self.flat = flat
+            self.gflat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+            self.gviews = self._views(self.gflat)
+            for p in self.params:
+                p.grad = None
+        return self
+
+    def gview(self, p):
+        return self.gviews[self._index(p)]
+
+    def _index(self, p):
+        for i, q in enumerate(self.params):
+            if q is p:
+                return i
+        raise KeyError("parameter is not part of this flat bucket")
+
+    def accumulating(self):
+        """True when the bucket already holds this step's gradients (a second backward before zero_grad)."""
+        return all(p.grad is not None and p.grad.data_ptr() == g.data_ptr() for p, g in zip(self.params, self.gviews))
+
+    def publish(self):
+        for p, g in zip(self.params, self.gviews):
+            if p.requires_grad:
+                p.grad = g

@@ -1,0 +1,180 @@
+"""GPU parity of the trainable head (forward AND backward, through the C ABI) against the golden
+vectors captured from the reference modules (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import load_npz, split_fixture, t
+
+pytestmark = pytest.mark.gpu
+
+FWD = dict(atol=3e-5, rtol=2e-4)
+BWD = dict(atol=3e-4, rtol=2e-3)
+
+
+@pytest.fixture(scope="module")
+def M():
+    import ser_amd  # noqa: F401
+    import ser_amd.models as models
+    assert torch.cuda.is_available()
+    return models
+
+
+def _close(got, want, msg="", **tol):
+    np.testing.assert_allclose(got.detach().cpu().numpy(), np.asarray(want), err_msg=msg, **tol)
+
+
+def _check_param_grads(module, grads):
+    named = dict(module.named_parameters())
+    for k, gw in grads.items():
+        p = named[k]
+        if p.grad is None:
+            assert float(gw.abs().max()) == 0.0, f"{k}: reference has a non-zero gradient, build has none"
+            continue
+        _close(p.grad, gw.numpy(), msg=k, **BWD)
+
+
+def test_cross_attention(M):
+    from ser_amd.models.cross_attention import CrossModalAttention
+    sd, gr, r = split_fixture(load_npz("cross.npz"))
+    m = CrossModalAttention(128, 128, shared_dim=64, num_heads=int(r["heads"]))
+    m.load_state_dict(sd)
+    m = m.cuda()
+    a, tt = t(r["a"]).cuda().requires_grad_(), t(r["t"]).cuda().requires_grad_()
+    ae, te = m(a, tt, t(r["a_mask"]).cuda(), t(r["t_mask"]).cuda())
+    _close(ae, r["a_enh"], **FWD)
+    _close(te, r["t_enh"], **FWD)
+    torch.autograd.backward([ae, te], [t(r["g_a_enh"]).cuda(), t(r["g_t_enh"]).cuda()])
+    _close(a.grad, r["grad_a"], **BWD)
+    _close(tt.grad, r["grad_t"], **BWD)
+    _check_param_grads(m, gr)
+
+
+def test_pooling(M):
+    from ser_amd.models.pooling import AttentiveStatsPooling
+    sd, gr, r = split_fixture(load_npz("pool.npz"))
+    m = AttentiveStatsPooling(128, hidden_dim=32)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    x = t(r["x"]).cuda().requires_grad_()
+    y = m(x, t(r["mask"]).cuda())
+    _close(y, r["y"], **FWD)
+    y.backward(t(r["g_y"]).cuda())
+    _close(x.grad, r["grad_x"], **BWD)
+    _check_param_grads(m, gr)
+
+
+def test_fusion(M):
+    sd, gr, r = split_fixture(load_npz("fusion.npz"))
+    m = M.FusionLayer(256, 256, 64)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    a, tv = t(r["a_vec"]).cuda().requires_grad_(), t(r["t_vec"]).cuda().requires_grad_()
+    f = m(a, tv)
+    _close(f, r["fused"], **FWD)
+    f.backward(t(r["g_fused"]).cuda())
+    _close(a.grad, r["grad_a_vec"], **BWD)
+    _close(tv.grad, r["grad_t_vec"], **BWD)
+    _check_param_grads(m, gr)
+
+
+def test_classifier_train_and_openmax(M):
+    from ser_amd.models.classifier import AdvancedOpenMaxClassifier
+    sd, gr, r = split_fixture(load_npz("classifier.npz"))
+    C, Lyr = int(r["num_labels"]), int(r["num_layers"])
+    m = AdvancedOpenMaxClassifier(input_dim=64, num_labels=C, num_layers=Lyr, base_dim=64, dropout=0.15)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = t(r["x"]).cuda().requires_grad_()
+    logits, unc, anchor = m(x, use_openmax=False, return_uncertainty=True)
+    _close(logits, r["logits"], **FWD)
+    _close(unc, r["unc"], **FWD)
+    assert float(anchor) == 0.0
+    torch.autograd.backward([logits, unc], [t(r["g_logits"]).cuda(), t(r["g_unc"]).cuda()])
+    _close(x.grad, r["grad_x"], **BWD)
+    _check_param_grads(m, gr)
+    # class indices bit-exact
+    assert torch.equal(logits.argmax(1).cpu(), t(r["logits"]).argmax(1))
+    m.eval()
+    with torch.no_grad():
+        _close(m(t(r["x"]).cuda(), use_openmax=True), r["logits_openmax_unfitted"], **FWD)
+        m.fit_weibull(t(r["fit_feats"]).cuda(), t(r["fit_labels"]).cuda())
+        for k in ("weibull_alpha", "weibull_beta", "weibull_tau", "activation_vectors"):
+            _close(getattr(m, k), r["fitted." + k], atol=1e-6, rtol=1e-5)
+        _close(m(t(r["x"]).cuda(), use_openmax=True), r["logits_openmax_fitted"], **FWD)
+
+
+def test_second_backward_accumulates(M):
+    sd, gr, r = split_fixture(load_npz("fusion.npz"))
+    m = M.FusionLayer(256, 256, 64)
+    m.load_state_dict(sd)
+    m = m.cuda()
+    for _ in range(2):
+        f = m(t(r["a_vec"]).cuda(), t(r["t_vec"]).cuda())
+        f.backward(t(r["g_fused"]).cuda())
+    named = dict(m.named_parameters())
+    for k, gw in gr.items():
+        _close(named[k].grad, 2 * gw.numpy(), msg=k, atol=6e-4, rtol=2e-3)
+    m.zero_grad(set_to_none=True)
+    f = m(t(r["a_vec"]).cuda(), t(r["t_vec"]).cuda())
+    f.backward(t(r["g_fused"]).cuda())
+    for k, gw in gr.items():
+        _close(named[k].grad, gw.numpy(), msg=k, **BWD)
+
+
+def test_train_loss_value_and_grads(M):
+    from ser_amd.models.losses import TrainLoss, LabelSmoothingCrossEntropy, ClassBalancedFocalLoss
+    from ser_amd.models.prototypes import PrototypeMemory
+    r = load_npz("losses.npz")
+    lg, un, fu = (t(r[k]).cuda().requires_grad_() for k in ("logits", "unc", "fused"))
+    lab = t(r["labels"]).cuda()
+    C = lg.shape[1]
+    pm = PrototypeMemory(C, fu.shape[1]).cuda()
+    with torch.no_grad():
+        pm.prototypes.copy_(t(r["prototypes"]))
+    crit = TrainLoss(C)
+    total = crit(lg, un, fu, pm.prototypes, lab, use_proto=True)
+    parts = crit.last_parts.cpu().numpy()
+    assert abs(float(total) - float(r["total"])) < 2e-5
+    for i, k in enumerate(("total", "ce", "focal", "unc_loss", "proto")):
+        assert abs(parts[i] - float(r[k])) < 1e-4, (k, parts[i], float(r[k]))
+    total.backward()
+    _close(lg.grad, r["grad_logits"], atol=2e-6, rtol=1e-3)
+    _close(un.grad, r["grad_unc"], atol=1e-7, rtol=1e-3)
+    _close(fu.grad, r["grad_fused"], atol=1e-7, rtol=1e-3)
+    _close(pm.prototypes.grad, r["grad_prototypes"], atol=1e-7, rtol=1e-3)
+    # reference-style separate criteria
+    assert abs(float(LabelSmoothingCrossEntropy(0.1)(t(r["logits"]).cuda(), lab)) - float(r["ce"])) < 2e-5
+    assert abs(float(ClassBalancedFocalLoss(num_classes=C)(t(r["logits"]).cuda(), lab)) - float(r["focal"])) < 2e-5
+    assert abs(float(pm.prototype_loss(t(r["fused"]).cuda(), lab)) - float(r["proto"])) < 1e-4
+
+
+def test_adamw_matches_torch_trajectory(M):
+    from ser_amd import _ops as O
+    r = load_npz("adamw.npz")
+    for name, mult, wd, col in (("p1", 1.5, 0.06, 0), ("p2", 1.0, 0.05, 1)):
+        p = t(r[f"{name}_0"]).cuda().contiguous()
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        for s in range(4):
+            base_lr = float(r["lrs"][s, col]) / mult
+            step = s + 1
+            hyper = torch.tensor([base_lr, 1 - 0.9 ** step, (1 - 0.999 ** step) ** 0.5], dtype=torch.float32).cuda()
+            O.adamw_(p, t(r[f"g{name[1]}_{s}"]).cuda().contiguous(), m, v, hyper, mult, wd)
+            _close(p, r[f"{name}_{s + 1}"], atol=2e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("M_,N,K", [(16, 512, 512), (3184, 256, 768), (50, 1, 128), (7, 4, 256), (130, 70, 33)])
+def test_gemm_f32_three_forms(M, M_, N, K):
+    from ser_amd import _ops as O
+    g = torch.Generator().manual_seed(3)
+    x, w, dy = torch.randn(M_, K, generator=g), torch.randn(N, K, generator=g), torch.randn(M_, N, generator=g)
+    b = torch.randn(N, generator=g)
+    y = O.linear_fwd(x.cuda(), w.cuda(), b.cuda(), O.ACT_TANH)
+    _close(y, torch.tanh(x.double() @ w.double().t() + b.double()).float(), atol=2e-5 * max(1, K ** 0.5 / 8), rtol=1e-4)
+    dx = O.linear_dgrad(dy.cuda(), w.cuda())
+    _close(dx, (dy.double() @ w.double()).float(), atol=1e-4, rtol=1e-4)
+    dW, db = torch.zeros(N, K).cuda(), torch.zeros(N).cuda()
+    O.linear_wgrad(dy.cuda(), x.cuda(), dW, db, accumulate=False)
+    O.linear_wgrad(dy.cuda(), x.cuda(), dW, db, accumulate=True)
+    _close(dW, 2 * (dy.double().t() @ x.double()).float(), atol=4e-4, rtol=2e-4)
+    _close(db, 2 * dy.double().sum(0).float(), atol=2e-4, rtol=2e-4)
