@@ -171,6 +171,7 @@ int ser_colsum(const float* x, int M, int N, int ld, float* out, int accumulate,
 int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream);
 int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);
 int ser_axpby(const float* x, float a, float b, long long n, float* y, void* stream); /* y = a x + b y */
+int ser_scale_dev(float* x, const float* s, long long n, void* stream);            /* x *= s[0], s on device */
 
 /* softmax(q k^T / sqrt(hd) + key mask) v of nn.MultiheadAttention (cross_attention.py:41,49;
  * torch nn/functional.py multi_head_attention_forward).  P [B,heads,Sq,Sk] is kept for backward. */

@@ -64,6 +64,12 @@ def axpby(x, y, a=1.0, b=1.0):
     return y
 
 
+def scale_dev_(x, s):
+    """x *= s[0] with s a device scalar (no host synchronisation)."""
+    L.check(L.lib.ser_scale_dev(L.ptr(x), L.ptr(s.reshape(1).contiguous()), x.numel(), L.stream_ptr()), "ser_scale_dev")
+    return x
+
+
 def ln_fwd(x, gamma, beta, eps=1e-5, x2=None, keep_z=None):
     """-> y, saved=(z, mean, rstd).  z is x itself unless a second addend is given."""
     rows, D = x.shape

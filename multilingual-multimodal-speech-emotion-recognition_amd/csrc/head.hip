@@ -184,6 +184,12 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, int act, long long n
   }
 }
 
+// x *= s[0]  (device scalar: keeps autograd's upstream gradient on the device, no host sync)
+__global__ void scale_dev_kernel(float* __restrict__ x, const float* __restrict__ s, long long n) {
+  const float f = s[0];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= f;
+}
+
 // y = a*x + b*y
 __global__ void axpby_kernel(const float* __restrict__ x, float a, float b, long long n, float* __restrict__ y) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -751,6 +757,13 @@ extern "C" int ser_act_bwd(const float* dy, const float* y, int act, long long n
 extern "C" int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream) {
   if (n <= 0) return SER_OK;
   hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, act, n, y);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_scale_dev(float* x, const float* s, long long n, void* stream) {
+  if (n <= 0) return SER_OK;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, s, n);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

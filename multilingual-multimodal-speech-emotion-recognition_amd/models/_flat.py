@@ -6,9 +6,20 @@ per tensor, (b) one fused AdamW launch per optimizer group, and (c) gradient ker
 straight into the bucket (no autograd-side copies).  `state_dict()` / `load_state_dict()` are
 unaffected because the nn.Parameters stay in place (their `.data` is re-pointed at the views).
 """
+import weakref
+
 import torch
 
 ALIGN = 64  # floats (256 B): keeps every view aligned for float4 kernels
+BUCKETS = weakref.WeakSet()   # every live bucket, so the optimizer / DP reducer can find a parameter's home
+
+
+def find_bucket(p):
+    for b in BUCKETS:
+        for i, q in enumerate(b.params):
+            if q is p:
+                return b, i
+    return None, -1
 
 
 class FlatParams:
@@ -22,6 +33,8 @@ class FlatParams:
             self.offsets.append(off)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
+        self.grad_ready_hook = None     # called with the bucket once its gradients are complete (DP overlap)
+        BUCKETS.add(self)
 
     def _views(self, buf):
         return [buf[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
@@ -64,3 +77,9 @@ class FlatParams:
         for p, g in zip(self.params, self.gviews):
             if p.requires_grad:
                 p.grad = g
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(self)
+
+    def padded_numel(self, i):
+        nxt = self.offsets[i + 1] if i + 1 < len(self.offsets) else self.total
+        return nxt - self.offsets[i]

@@ -25,11 +25,9 @@ class _TrainLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _):
         dl, du, df, dp = ctx.saved_tensors
-        # upstream scale (normally exactly 1): applied by the axpby kernel, not by torch arithmetic
-        if not (g.numel() == 1 and float(g) == 1.0):
-            s = float(g)
-            for t in (dl, du, df, dp):
-                O.axpby(t, t, s, 0.0)
+        # upstream scale stays on the device (no .item()): the step can be captured into a hipGraph
+        for t in (dl, du, df, dp):
+            O.scale_dev_(t, g)
         return dl, du, df, dp, None, None
 
 
@@ -92,8 +90,7 @@ class _FocalOnlyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (d1,) = ctx.saved_tensors
-        if float(g) != 1.0:
-            O.axpby(d1, d1, float(g), 0.0)
+        O.scale_dev_(d1, g)
         return d1, None, None, None
 
 

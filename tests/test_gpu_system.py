@@ -1,0 +1,125 @@
+"""End-to-end GPU parity of one training step of the assembled hot path (ref train.py:145-177)
+against the CPU oracle with torch autograd: logits, loss, gradients, one AdamW update; and
+graph-captured stepping == eager stepping."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ser_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(seed, B=4, T=4000, S=9, vocab=1000, C=4):
+    g = torch.Generator().manual_seed(seed)
+    wave = 0.1 * torch.randn(B, T, generator=g)
+    ids = torch.randint(4, vocab, (B, S), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    mask = torch.ones(B, S)
+    ids[1, S - 3:] = 1
+    ids[1, S - 4] = 2
+    mask[1, S - 3:] = 0
+    labels = torch.randint(0, C, (B,), generator=g)
+    return wave, ids, mask, labels
+
+
+def _oracle_step(sds, wave, ids, mask, labels, a_cfg, t_cfg):
+    """Oracle forward + autograd backward over the trainable head (encoders frozen)."""
+    leaf = {k: {n: v.clone().requires_grad_(v.dtype.is_floating_point and not n.startswith("encoder."))
+                for n, v in sd.items()} for k, sd in sds.items()}
+    out = O.full_forward(leaf, list(wave), ids, mask, a_cfg, t_cfg, num_layers=3, heads=2, use_openmax=False, training=True)
+    loss = O.train_loss(out["logits"], out["unc"], out["fused"], leaf["prototypes"]["prototypes"], labels, 4)
+    loss.backward()
+    return out, loss, leaf
+
+
+def test_train_step_matches_oracle():
+    import __graft_entry__ as ge
+    dev = torch.device("cuda:0")
+    sysm, wc, xc = ge._small_system(dev)
+    sysm.train()
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    wave, ids, mask, labels = _batch(7)
+    sds = {k: {n: v.detach().cpu().clone() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
+    out, ref_loss, leaf = _oracle_step(sds, wave, ids, mask, labels, a_cfg, t_cfg)
+
+    loss, logits = sysm.loss(wave.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+    loss.backward()
+    assert (logits.cpu() - out["logits"]).abs().max().item() < 1e-3          # north-star tolerance
+    assert torch.equal(logits.argmax(1).cpu(), out["logits"].argmax(1))      # class indices bit-exact
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    worst = 0.0
+    for key in sysm.CKPT_KEYS:
+        named = dict(getattr(sysm, key).named_parameters())
+        for n, v in leaf[key].items():
+            if v.grad is None or n not in named:
+                continue
+            got = named[n].grad
+            if got is None:
+                assert v.grad.abs().max().item() == 0.0, f"{key}.{n}: missing gradient"
+                continue
+            denom = max(v.grad.abs().max().item(), 1e-3)
+            rel = (got.cpu() - v.grad).abs().max().item() / denom
+            worst = max(worst, rel)
+            assert rel < 2e-2, f"{key}.{n}: gradient differs from the oracle (rel {rel:.3e})"
+    # one AdamW step, lr 1e-3 with the reference's group multipliers
+    opt = sysm.make_optimizer(lr=1e-3)
+    opt.step()
+    lr_mult = dict(audio_encoder=0.1, text_encoder=0.1, cross=1, pool_a=1, pool_t=1, fusion=1, prototypes=1)
+    wd = dict(audio_encoder=.025, text_encoder=.025, cross=.05, pool_a=.05, pool_t=.05, fusion=.05, prototypes=.05)
+    for key in ("cross", "fusion", "prototypes", "audio_encoder"):
+        named = dict(getattr(sysm, key).named_parameters())
+        for n, v in leaf[key].items():
+            if v.grad is None or n not in named or named[n].grad is None:
+                continue
+            want, _, _ = O.adamw_step(v.detach(), v.grad, torch.zeros_like(v), torch.zeros_like(v), 1, 1e-3 * lr_mult[key], wd[key])
+            # Adam's first step moves every weight by ~lr*sign(g): compare the update, not the weight
+            upd_got, upd_want = named[n].detach().cpu() - v.detach(), want - v.detach()
+            big = v.grad.abs() > 1e-6
+            if big.any():
+                assert (upd_got - upd_want)[big].abs().max().item() < 2e-5, f"{key}.{n}: AdamW update differs"
+
+
+def test_graph_step_equals_eager_step():
+    import __graft_entry__ as ge
+    from ser_amd.system import TrainStepper
+    from ser_amd.optim import WarmupCosine
+    dev = torch.device("cuda:0")
+    sys_a, wc, xc = ge._small_system(dev)
+    sys_b, _, _ = ge._small_system(dev)
+    sys_b.load_state_dict(sys_a.state_dict())
+    steppers = []
+    for s, graph in ((sys_a, False), (sys_b, True)):
+        s.train()
+        opt = s.make_optimizer(lr=1e-3)
+        steppers.append(TrainStepper(s, opt, WarmupCosine(opt, 10, 0.0), use_graph=graph))
+    for it in range(3):
+        batch = [t.to(dev) for t in _batch(100 + it)]
+        la = steppers[0].step(*batch)
+        lb = steppers[1].step(*batch)
+        torch.cuda.synchronize()
+        assert abs(la.item() - lb.item()) < 1e-6, f"step {it}: eager {la.item()} vs graph {lb.item()}"
+    for (n, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
+        assert torch.equal(pa, pb), f"{n}: parameters diverged between eager and graph stepping"
+
+
+def test_variable_length_clips_pad_like_reference():
+    import __graft_entry__ as ge
+    dev = torch.device("cuda:0")
+    sysm, wc, xc = ge._small_system(dev)
+    sysm.eval()
+    a_cfg, _ = ge.oracle_cfgs(wc, xc)
+    g = torch.Generator().manual_seed(3)
+    waves = [0.1 * torch.randn(n, generator=g) for n in (4000, 3200, 4000, 2400)]
+    seq, mask = sysm.audio_encoder(waves, None)
+    sd = {n: v.detach().cpu() for n, v in sysm.audio_encoder.state_dict().items()}
+    want, wmask = O.audio_encoder_forward(sd, waves, a_cfg)
+    assert seq.shape == want.shape and torch.equal(mask.cpu(), wmask)
+    assert (seq.cpu() - want).abs().max().item() < 5e-4
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
