@@ -73,6 +73,11 @@ int ser_layernorm(const float* x, const float* x2, const float* gamma, const flo
 int ser_self_attention(const uint16_t* qkv_hi, const uint16_t* qkv_lo, const float* key_mask, int B,
                        int S, int heads, uint16_t* ctx_hi, uint16_t* ctx_lo, void* stream);
 
+/* Measurement aid (bench.py roofline leg): HIP events around every ser_gemm_bf16 launch between
+ * start and stop; stop returns summed kernel ms, algorithmic FLOPs (2*M*N*K) and the launch count. */
+int ser_prof_gemm_start(void);
+int ser_prof_gemm_stop(double* total_ms, double* total_flops, long long* launches);
+
 /* ---------------------------------------------------------------------------------------------
  * frozen encoders, forward only
  * ------------------------------------------------------------------------------------------- */

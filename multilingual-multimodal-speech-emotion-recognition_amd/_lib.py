@@ -70,6 +70,8 @@ def _sig(name, restype, *argtypes):
 
 _sig("ser_last_error_string", C.c_char_p)
 _sig("ser_abi_version", i32)
+_sig("ser_prof_gemm_start", i32)
+_sig("ser_prof_gemm_stop", i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong))
 _sig("ser_split_bf16", i32, vp, vp, vp, i64, vp)
 _sig("ser_gemm_bf16_nt", i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp)
 _sig("ser_layernorm", i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp)

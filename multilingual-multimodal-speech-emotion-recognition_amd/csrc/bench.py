@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one training step (forward, loss, backward, AdamW) of the multimodal
+SER model on synthetic RAVDESS-shaped batches — BASELINE.json configs[1]:
+4 s @ 16 kHz waveforms + 32-token text, batch 16 per GPU, Wav2Vec2-Base + XLM-R-Base frozen,
+adapters + cross-attention + pooling + fusion + 35-block classifier trained.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  `value` = utterances/s over all ranks, inputs resident in HBM.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+SR = 16000
+# algorithmic FLOPs per utterance (2 x MAC), SURVEY.md section 8(d), config 2/3 shapes (S_a=199, S_t=32, Base)
+FLOP_FWD_PER_UTT = 63.4e9
+FLOP_TRAIN_FROZEN_PER_UTT = 65.4e9
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def hf_configs(stress=False):
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    if stress:   # BASELINE config 5: WavLM-Large-sized encoders, random init
+        wc = Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096)
+        xc = XLMRobertaConfig(vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
+                              intermediate_size=4096, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                              pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    else:
+        wc = Wav2Vec2Config()      # == facebook/wav2vec2-base architecture
+        xc = XLMRobertaConfig(vocab_size=250002, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                              pad_token_id=1, bos_token_id=0, eos_token_id=2)     # == xlm-roberta-base architecture
+    return wc, xc
+
+
+def build_system(precision, device, num_labels=4, stress=False):
+    import ser_amd  # noqa: F401
+    from ser_amd.models import AudioEncoder, TextEncoder
+    from ser_amd.system import SERSystem
+    wc, xc = hf_configs(stress)
+    torch.manual_seed(0)            # identical random-init replicas on every rank
+    ae = AudioEncoder(hf_config=wc, use_quality_gates=False, use_audio_conditioning=False, precision=precision)
+    te = TextEncoder(hf_config=xc, precision=precision)
+    sysm = SERSystem(ae, te, num_labels=num_labels)
+    return sysm.to(device), wc, xc
+
+
+def synth_batch(B, seconds, tokens, vocab, num_labels, seed):
+    g = torch.Generator().manual_seed(seed)
+    wave = 0.1 * torch.randn(B, int(SR * seconds), generator=g)
+    ids = torch.randint(4, vocab, (B, tokens), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    mask = torch.ones(B, tokens)
+    labels = torch.randint(0, num_labels, (B,), generator=g)
+    return wave, ids, mask, labels
+
+
+def cpu_baseline_and_parity(sysm, wc, xc, args, dev):
+    """Oracle (CPU restatement) timed on the host cores on a bounded sample of the same workload, and the
+    logits max-abs-err of the HIP path against it on that sample."""
+    import __graft_entry__ as ge
+    from oracle.cpu_step import OracleTrainer, time_steps
+    Bc = args.cpu_batch
+    wave, ids, mask, labels = synth_batch(Bc, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels, 4321)
+    sds = {k: {n: v.detach().cpu() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    tr = OracleTrainer(sds, a_cfg, t_cfg, num_layers=35, heads=8, num_labels=sysm.num_labels)
+    ref = tr.forward(list(wave), ids, mask, use_openmax=False, training=True)
+    sysm.train()
+    with torch.no_grad():
+        logits = sysm(wave.to(dev), ids.to(dev), mask.to(dev), use_openmax=False).cpu()
+    err = (logits - ref["logits"]).abs().max().item()
+    same = bool(torch.equal(logits.argmax(1), ref["logits"].argmax(1)))
+    sec = time_steps(tr, list(wave), ids, mask, labels, warmup=1, steps=args.cpu_steps)
+    ncores = torch.get_num_threads()
+    base = dict(value=round(Bc / sec, 4), unit="utt/s", cores=ncores, kind="port",
+                sample=f"{args.cpu_steps} timed train steps (fwd+loss+bwd+AdamW) of oracle/cpu_step.py at batch {Bc}, "
+                       f"{args.seconds:g} s audio + {args.tokens} tokens, PyTorch-CPU fp32, {ncores} threads")
+    return base, err, same
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--tokens", type=int, default=32)
+    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--stress", action="store_true", help="BASELINE config 5 encoder sizes (1024-d, 24 layers)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback of the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ser_amd.system import GradReducer, TrainStepper
+    from ser_amd import _lib as L
+    sysm, wc, xc = build_system(args.precision, dev, stress=args.stress)
+    sysm.train()
+    opt = sysm.make_optimizer(lr=1e-4)
+    reducer = GradReducer(sysm) if world > 1 else None
+    use_graph = not args.no_graph
+    stepper = TrainStepper(sysm, opt, None, reducer, use_graph=use_graph)
+    batch = [t.to(dev) for t in synth_batch(args.batch, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels, 1234 + rank)]
+
+    for _ in range(max(1, args.warmup)):
+        stepper.step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stepper.step(*batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * args.steps / elapsed
+    loss = float(stepper.loss.item())
+
+    # ---- roofline leg: HIP events around every launch of the dominant kernel (the encoder MFMA GEMM) -------
+    roof = None
+    if rank == 0:
+        eager = TrainStepper(sysm, opt, None, None, use_graph=False)
+        L.check(L.lib.ser_prof_gemm_start())
+        nprof = 3
+        for _ in range(nprof):
+            eager.step(*batch)
+        ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
+        L.check(L.lib.ser_prof_gemm_stop(C.byref(ms), C.byref(fl), C.byref(n)))
+        achieved = fl.value / (ms.value * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    kernel="gemm_bf16_nt_kernel", launches_per_step=n.value // nprof,
+                    avg_launch_us=round(ms.value * 1e3 / max(1, n.value), 2),
+                    algorithmic_gflop_per_step=round(fl.value / nprof / 1e9, 1),
+                    mfma_products_per_mac=3 if args.precision == "bf16x3" else 1)
+    if world > 1:
+        dist.barrier()
+
+    out = None
+    if rank == 0:
+        cpu, err, same = (None, None, None)
+        if not args.no_cpu_baseline:
+            cpu, err, same = cpu_baseline_and_parity(sysm, wc, xc, args, dev)
+        step_tflops = value * FLOP_TRAIN_FROZEN_PER_UTT / 1e12 if not args.stress and args.seconds == 4.0 else None
+        out = {
+            "metric": "utterances/sec (train step, 4s@16kHz + 32 tok)", "value": round(value, 2), "unit": "utt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "RAVDESS-shaped synthetic: %gs@16kHz waveform + %d-token text, batch %d per GPU, "
+                                   "Wav2Vec2-Base + XLM-R-Base frozen (random init), adapters + cross-attention + pooling + "
+                                   "gated fusion + 35-block OpenMax classifier trained, AdamW" % (args.seconds, args.tokens, args.batch),
+                       "global_batch": world * args.batch, "precision": args.precision,
+                       "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "stress_sizes": bool(args.stress)},
+            "roofline": roof, "cpu_baseline": cpu,
+            "logit_max_abs_err_vs_cpu_oracle": err, "class_indices_equal": same,
+            "whole_step_algorithmic_tflops": None if step_tflops is None else round(step_tflops, 2),
+            "loss": round(loss, 5),
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,7 @@
 // (16-byte chunk index XOR row&7) is applied to the per-lane SOURCE address and again on the
 // ds_read_b128 side (cdna_hip_programming.md rule 21).  Two LDS stages: the loads of k-tile t+1
 // are in flight while tile t is multiplied; one barrier per k-tile.
+#include <vector>
 #include "ser_common.h"
 
 namespace {
@@ -156,14 +157,33 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
   }
 }
 
+// ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
+struct ProfRec {
+  hipEvent_t e0, e1;
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
 template <int BM, int BN>
 int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
   dim3 grid(tiles, 1, g.nb1 * g.nb2), block(256);
+  ProfRec rec;
+  if (g_prof_on) {
+    SER_CHECK_HIP(hipEventCreate(&rec.e0));
+    SER_CHECK_HIP(hipEventCreate(&rec.e1));
+    rec.flops = 2.0 * g.M * (double)g.N * g.K * g.nb1 * g.nb2;   // algorithmic (one product per MAC)
+    SER_CHECK_HIP(hipEventRecord(rec.e0, st));
+  }
   if (g.a_lo && g.w_lo)
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, 0, st, g);
   else
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, 0, st, g);
+  if (g_prof_on) {
+    SER_CHECK_HIP(hipEventRecord(rec.e1, st));
+    g_prof.push_back(rec);
+  }
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
@@ -203,4 +223,30 @@ extern "C" int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int 
   g.c_f32 = c_f32; g.c_hi = c_hi; g.c_lo = c_lo; g.ldc = ldc;
   if ((a_lo == nullptr) != (w_lo == nullptr)) { g.a_lo = nullptr; g.w_lo = nullptr; }
   return ser_launch_gemm_bf16(g, (hipStream_t)stream);
+}
+
+// Per-launch HIP-event timing of the encoder GEMM kernel.  start: begin recording; stop: synchronise
+// on the recorded events and return total kernel milliseconds, algorithmic FLOPs and launch count.
+extern "C" int ser_prof_gemm_start(void) {
+  g_prof.clear();
+  g_prof_on = true;
+  return SER_OK;
+}
+extern "C" int ser_prof_gemm_stop(double* total_ms, double* total_flops, long long* launches) {
+  g_prof_on = false;
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_prof) {
+    SER_CHECK_HIP(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    SER_CHECK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t;
+    fl += r.flops;
+    hipEventDestroy(r.e0);
+    hipEventDestroy(r.e1);
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (long long)g_prof.size();
+  g_prof.clear();
+  return SER_OK;
 }
