@@ -241,8 +241,8 @@ extern "C" int ser_prof_gemm_stop(double* total_ms, double* total_flops, long lo
     SER_CHECK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
     ms += t;
     fl += r.flops;
-    hipEventDestroy(r.e0);
-    hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
