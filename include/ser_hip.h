@@ -164,6 +164,17 @@ int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, l
                  long long sbn, int M, int N, int K, const float* bias, int act, const float* residual,
                  int ldr, float* c, int ldc, int accumulate, void* stream);
 
+/* The three products of a Linear layer with shape-specialised kernels behind them: M <= 16 rows (the
+ * classifier / fusion run at M = batch) stream the weights straight into MFMA operands; wgrad over
+ * many tokens splits the reduction over workgroups (workspace: ser_linear_wgrad_workspace_bytes) and
+ * folds the bias gradient (column sums of dy) into the same pass. */
+int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
+                   float* y, int M, int N, int K, void* stream);
+int ser_linear_dgrad(const float* dy, const float* W, float* dx, int M, int N, int K, int accumulate, void* stream);
+size_t ser_linear_wgrad_workspace_bytes(int M, int N, int K);
+int ser_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
 /* nn.LayerNorm forward keeping z = x (+ x2), mean, rstd for backward (cross_attention.py:28-29,
  * classifier.py:79,107,118,125); backward gives dx (+ dx_add) and dgamma/dbeta. */
 int ser_layernorm_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float eps,

@@ -20,8 +20,8 @@ def linear_fwd(x, W, b=None, act=ACT_NONE, residual=None, out=None):
     M, K = x.shape
     N = W.shape[0]
     y = out if out is not None else empty(M, N, like=x)
-    L.check(L.lib.ser_gemm_f32(L.ptr(x), K, 1, L.ptr(W), 1, K, M, N, K, L.ptr(b), act, L.ptr(residual), N, L.ptr(y), N, 0,
-                               L.stream_ptr()), "ser_gemm_f32(fwd)")
+    L.check(L.lib.ser_linear_fwd(L.ptr(x), L.ptr(W), L.ptr(b), act, L.ptr(residual), N, L.ptr(y), M, N, K, L.stream_ptr()),
+            "ser_linear_fwd")
     return y
 
 
@@ -30,20 +30,19 @@ def linear_dgrad(dy, W, out=None, accumulate=False):
     M, N = dy.shape
     K = W.shape[1]
     dx = out if out is not None else empty(M, K, like=dy)
-    L.check(L.lib.ser_gemm_f32(L.ptr(dy), N, 1, L.ptr(W), K, 1, M, K, N, None, ACT_NONE, None, 0, L.ptr(dx), K,
-                               1 if accumulate else 0, L.stream_ptr()), "ser_gemm_f32(dgrad)")
+    L.check(L.lib.ser_linear_dgrad(L.ptr(dy), L.ptr(W), L.ptr(dx), M, N, K, 1 if accumulate else 0, L.stream_ptr()),
+            "ser_linear_dgrad")
     return dx
 
 
 def linear_wgrad(dy, x, dW, db=None, accumulate=False):
-    """dW[N,K] (+)= dy[M,N]^T x[M,K];  db[N] (+)= colsum(dy)."""
+    """dW[N,K] (+)= dy[M,N]^T x[M,K];  db[N] (+)= colsum(dy) in the same pass."""
     M, N = dy.shape
     K = x.shape[1]
-    acc = 1 if accumulate else 0
-    L.check(L.lib.ser_gemm_f32(L.ptr(dy), 1, N, L.ptr(x), K, 1, N, K, M, None, ACT_NONE, None, 0, L.ptr(dW), K, acc,
-                               L.stream_ptr()), "ser_gemm_f32(wgrad)")
-    if db is not None:
-        L.check(L.lib.ser_colsum(L.ptr(dy), M, N, N, L.ptr(db), acc, L.stream_ptr()), "ser_colsum")
+    nbytes = L.lib.ser_linear_wgrad_workspace_bytes(M, N, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if nbytes else None
+    L.check(L.lib.ser_linear_wgrad(L.ptr(dy), L.ptr(x), L.ptr(dW), L.ptr(db), M, N, K, 1 if accumulate else 0, L.ptr(ws),
+                                   nbytes, L.stream_ptr()), "ser_linear_wgrad")
 
 
 def act_fwd(x, act):

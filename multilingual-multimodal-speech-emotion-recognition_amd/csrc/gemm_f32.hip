@@ -25,6 +25,11 @@ struct SerGemmF32Args {
   const float* residual;
   int ldr;
   int accumulate;
+  // split-K (wgrad over many tokens): grid.z slices of k_chunk; partial tiles go to ws[z][M][N] and the
+  // row sums of A (= bias gradient when A = dy^T) to ws_rowsum[z][M]; a reduce kernel finishes
+  int k_chunk;
+  float* ws;
+  float* ws_rowsum;
 };
 
 namespace {
@@ -94,9 +99,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const SerGemmF32Args g) {
 
   TileRegs<BM> ra;
   TileRegs<BN> rb;
-  const int nk = (g.K + FBK - 1) / FBK;
-  load_tile<BM>(ra, g.a, g.sam, g.sak, m0, g.M, 0, g.K, tid, a_kfast);
-  load_tile<BN>(rb, g.b, g.sbn, g.sbk, n0, g.N, 0, g.K, tid, b_kfast);
+  const int kbeg = g.k_chunk ? blockIdx.z * g.k_chunk : 0;
+  const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
+  const int nk = (kend - kbeg + FBK - 1) / FBK;
+  float rowsum = 0.f;
+  const bool want_rowsum = g.ws_rowsum != nullptr && blockIdx.x == 0 && tid < BM;
+  load_tile<BM>(ra, g.a, g.sam, g.sak, m0, g.M, kbeg, kend, tid, a_kfast);
+  load_tile<BN>(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid, b_kfast);
   store_tile<BM, LDA>(ra, As[0], tid, a_kfast);
   store_tile<BN, LDB>(rb, Bs[0], tid, b_kfast);
   __syncthreads();
@@ -104,8 +113,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const SerGemmF32Args g) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_tile<BM>(ra, g.a, g.sam, g.sak, m0, g.M, (kt + 1) * FBK, g.K, tid, a_kfast);
-      load_tile<BN>(rb, g.b, g.sbn, g.sbk, n0, g.N, (kt + 1) * FBK, g.K, tid, b_kfast);
+      load_tile<BM>(ra, g.a, g.sam, g.sak, m0, g.M, kbeg + (kt + 1) * FBK, kend, tid, a_kfast);
+      load_tile<BN>(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg + (kt + 1) * FBK, kend, tid, b_kfast);
+    }
+    if (want_rowsum) {
+#pragma unroll
+      for (int kk = 0; kk < FBK; ++kk) rowsum += As[cur][kk * LDA + tid];
     }
 #pragma unroll
     for (int ks = 0; ks < FBK / 4; ++ks) {
@@ -126,6 +139,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const SerGemmF32Args g) {
     __syncthreads();
   }
 
+  if (want_rowsum && m0 + tid < g.M) g.ws_rowsum[(long long)blockIdx.z * g.M + m0 + tid] = rowsum;
+  if (g.ws) {   // split-K partial: raw accumulators to the workspace slice
+    float* wsz = g.ws + (long long)blockIdx.z * g.M * g.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + fr;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * WM + i * 16 + fq * 4 + r;
+          if (m < g.M) wsz[(long long)m * g.N + n] = acc[i][j][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + fr;
@@ -145,13 +175,197 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const SerGemmF32Args g) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Skinny products for M <= 16 rows (the 35-block classifier, fusion and heads run at M = batch):
+// weights are streamed straight from global memory into MFMA operand registers, 16 B per lane,
+// every load of a wave issued up front; K (or N) is split over the waves of the workgroup and
+// reduced through LDS.  No operand tile goes through LDS: each weight byte is used once.
+// ------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, int act,
+                                                                const float* __restrict__ residual, int ldr,
+                                                                float* __restrict__ y, int M, int N, int K) {
+  __shared__ float red[WAVES][64][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const float* xr = x + (long long)min(i, M - 1) * K + q * 4;
+  const float* wr = W + (long long)min(n0 + i, N - 1) * K + q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nchunk = K >> 4;
+  const int nit = (nchunk - w + WAVES - 1) / WAVES;   // this wave's chunks: w, w+WAVES, ...
+  for (int it = 0; it < nit; it += 4) {               // 8 x 16-B loads in flight per lane before the MFMAs
+    float4 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = w + (it + u) * WAVES;
+      const bool ok = it + u < nit;
+      a[u] = ok ? *(const float4*)(xr + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      b[u] = ok ? *(const float4*)(wr + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+  __syncthreads();
+  if (w == 0) {
+    const int n = n0 + i;
+    if (n < N) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) v += red[ww][lane][r];
+        v = act_f32(v + bv, act);
+        if (residual) v += residual[(long long)m * ldr + n];
+        y[(long long)m * N + n] = v;
+      }
+    }
+  }
+}
+
+// dx[M,Kc] = dy[M,N] . W[N,Kc]   (reduction over N split across the waves)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                                  float* __restrict__ dx, int M, int N, int Kc,
+                                                                  int accumulate) {
+  __shared__ float red[WAVES][64][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int c0 = blockIdx.x * 64 + 4 * i;
+  const bool cok = c0 < Kc;
+  const float* dyr = dy + (long long)min(i, M - 1) * N;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (N + 3) >> 2;
+  const int nit = (nsteps - w + WAVES - 1) / WAVES;
+  for (int it = 0; it < nit; it += 4) {
+    float a[4];
+    float4 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int n = (w + (it + u) * WAVES) * 4 + q;
+      const bool ok = it + u < nit && n < N;
+      a[u] = ok ? dyr[n] : 0.f;
+      b[u] = (ok && cok) ? *(const float4*)(W + (long long)n * Kc + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].w, acc[3], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][lane][t * 4 + r] = acc[t][r];
+  __syncthreads();
+  if (w == 0 && cok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = q * 4 + r;
+      if (m >= M) continue;
+      float v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        v[t] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) v[t] += red[ww][lane][t * 4 + r];
+      }
+      float4* dst = (float4*)(dx + (long long)m * Kc + c0);
+      float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *dst = o;
+    }
+  }
+}
+
+// dW[N,Kc] (+)= dy[M<=16,N]^T . x[M,Kc] ; db[N] (+)= sum_m dy[m,n]
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           float* __restrict__ dW, float* __restrict__ db, int M, int N,
+                                                           int Kc, int accumulate) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * 64 + w * 16;
+  const int c0 = blockIdx.x * 64 + 4 * i;
+  const bool cok = c0 < Kc, nok = n0 + i < N;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int m = 4 * s + q;
+    const bool mok = m < M;
+    const float a = (mok && nok) ? dy[(long long)m * N + n0 + i] : 0.f;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mok && cok) b = *(const float4*)(x + (long long)m * Kc + c0);
+    asum += a;
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
+  }
+  if (cok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + q * 4 + r;
+      if (n >= N) continue;
+      float4* dst = (float4*)(dW + (long long)n * Kc + c0);
+      float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *dst = o;
+    }
+  }
+  if (db && blockIdx.x == 0) {
+    asum += __shfl_xor(asum, 16, 64);
+    asum += __shfl_xor(asum, 32, 64);
+    if (q == 0 && nok) db[n0 + i] = accumulate ? db[n0 + i] + asum : asum;
+  }
+}
+
+// C[m,n] (+)= sum_z ws[z][m][n] ; rowsum_out[m] (+)= sum_z ws_rowsum[z][m]
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_rowsum, int splits,
+                                     long long MN, int M, float* __restrict__ c, float* __restrict__ rowsum_out,
+                                     int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < MN) {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += ws[(long long)z * MN + i];
+    c[i] = accumulate ? c[i] + v : v;
+  }
+  if (rowsum_out && i < M) {
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += ws_rowsum[(long long)z * M + i];
+    rowsum_out[i] = accumulate ? rowsum_out[i] + v : v;
+  }
+}
+
 }  // namespace
 
 int ser_launch_gemm_f32(const SerGemmF32Args& g, hipStream_t st) {
   SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
   SER_REQUIRE(g.a && g.b && g.c, "gemm_f32: null operand");
   dim3 block(256);
-  if (g.M <= 16) {
+  const int zs = g.k_chunk ? ceil_div(g.K, g.k_chunk) : 1;
+  if (g.k_chunk) {
+    dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), zs);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, block, 0, st, g);
+  } else if (g.M <= 16) {
     dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 16));
     hipLaunchKernelGGL((gemm_f32_kernel<16, 64>), grid, block, 0, st, g);
   } else if (g.N <= 16) {
@@ -172,5 +386,75 @@ extern "C" int ser_gemm_f32(const float* a, long long sam, long long sak, const 
   g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr; g.accumulate = accumulate;
+  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr;
   return ser_launch_gemm_f32(g, (hipStream_t)stream);
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// y[M,N] = act(x[M,K] W[N,K]^T + b) + residual
+extern "C" int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
+                              float* y, int M, int N, int K, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 16 && K % 16 == 0 && aligned16(x) && aligned16(W)) {
+    SER_REQUIRE(M > 0 && N > 0, "linear_fwd: empty problem");
+    if (K >= 256)
+      hipLaunchKernelGGL(skinny_fwd_kernel<8>, dim3(ceil_div(N, 16)), dim3(512), 0, st, x, W, bias, act, residual, ldr, y, M, N, K);
+    else
+      hipLaunchKernelGGL(skinny_fwd_kernel<2>, dim3(ceil_div(N, 16)), dim3(128), 0, st, x, W, bias, act, residual, ldr, y, M, N, K);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
+  return ser_gemm_f32(x, K, 1, W, 1, K, M, N, K, bias, act, residual, ldr, y, N, 0, stream);
+}
+
+// dx[M,K] (+)= dy[M,N] W[N,K]
+extern "C" int ser_linear_dgrad(const float* dy, const float* W, float* dx, int M, int N, int K, int accumulate,
+                                void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 16 && K % 4 == 0 && aligned16(W) && aligned16(dx)) {
+    SER_REQUIRE(M > 0 && N > 0 && K > 0, "linear_dgrad: empty problem");
+    if (N >= 128)
+      hipLaunchKernelGGL(skinny_dgrad_kernel<8>, dim3(ceil_div(K, 64)), dim3(512), 0, st, dy, W, dx, M, N, K, accumulate);
+    else
+      hipLaunchKernelGGL(skinny_dgrad_kernel<2>, dim3(ceil_div(K, 64)), dim3(128), 0, st, dy, W, dx, M, N, K, accumulate);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
+  return ser_gemm_f32(dy, N, 1, W, K, 1, M, K, N, nullptr, SER_ACT_NONE, nullptr, 0, dx, K, accumulate, stream);
+}
+
+extern "C" size_t ser_linear_wgrad_workspace_bytes(int M, int N, int K) {
+  if (M <= 16) return 0;
+  const int splits = ceil_div(M, 256);
+  return ((size_t)splits * N * K + (size_t)splits * N) * sizeof(float) + 256;
+}
+
+// dW[N,K] (+)= dy[M,N]^T x[M,K] ; db[N] (+)= colsum(dy)   (db may be NULL)
+extern "C" int ser_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K,
+                                int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SER_REQUIRE(M > 0 && N > 0 && K > 0, "linear_wgrad: empty problem");
+  if (M <= 16 && K % 4 == 0 && aligned16(x) && aligned16(dW)) {
+    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(ceil_div(K, 64), ceil_div(N, 64)), dim3(256), 0, st, dy, x, dW, db, M, N, K,
+                       accumulate);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
+  // many rows (tokens): split the reduction over workgroups, partial tiles + fused bias row sums, then reduce
+  SER_REQUIRE(workspace && workspace_bytes >= ser_linear_wgrad_workspace_bytes(M, N, K), "linear_wgrad: workspace too small");
+  const int chunk = 256, splits = ceil_div(M, chunk);
+  SerGemmF32Args g;
+  g.a = dy; g.b = x; g.c = dW; g.M = N; g.N = K; g.K = M;
+  g.sam = 1; g.sak = N; g.sbk = K; g.sbn = 1; g.ldc = K;
+  g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = accumulate;
+  g.k_chunk = chunk;
+  g.ws = (float*)workspace;
+  g.ws_rowsum = db ? g.ws + (size_t)splits * N * K : nullptr;
+  SER_TRY(ser_launch_gemm_f32(g, st));
+  const long long MN = (long long)N * K;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, st, g.ws, g.ws_rowsum, splits, MN, N,
+                     dW, db, accumulate);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
 }
