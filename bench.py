@@ -96,7 +96,8 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--tokens", type=int, default=32)
-    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3")
+    ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16",
+                    help="bf16: one bf16 MFMA per product (BASELINE config). bf16x3: split-operand parity mode")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)

@@ -58,15 +58,31 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
   constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
   constexpr int STAGE = (A_TILE + W_TILE) * NPL;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  constexpr int EPI_BYTES = BM * (BN + 4) * 4;        // fp32 tile staged for the coalesced epilogue
+  constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  // blockIdx -> tile: (1) XCD-contiguous chunks (blocks b, b+8, ... share an XCD's L2, so give each XCD a
+  // contiguous run of tiles), (2) inside a run, GROUP_M x tiles_n super-tiles so the ~32 workgroups resident on
+  // one XCD touch few distinct A and W panels at a time.  Pure speed: any placement gives the same result.
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  int tile_m, tile_n;
+  {
+    const int nt = tiles_m * tiles_n, bid = blockIdx.x;
+    const int q = nt >> 3, r = nt & 7, xcd = bid & 7, local = bid >> 3;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (t / per_group) * GROUP_M;
+    const int gsz = min(GROUP_M, tiles_m - first_m);
+    tile_m = first_m + (t % per_group) % gsz;
+    tile_n = (t % per_group) / gsz;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
 
@@ -127,30 +143,80 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
     }
   }
 
-  // epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  // epilogue: accumulators -> LDS (row-major fp32 tile) -> coalesced 16-byte global stores.
+  // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  constexpr int LDT = BN + 4;                       // floats; +4 keeps the two half-waves on different banks
+  __syncthreads();                                   // every wave is done reading the last k-tile
+  float* tile = (float*)lds;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        tile[(wm * WM + i * 16 + fq * 4 + r) * LDT + wn * WN + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
   const long long coff = b1 * g.sc1 + b2 * g.sc2;
   const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
   const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
+  constexpr int TPR = BN / 8;                        // threads per row, 8 columns each
+  constexpr int RPI = 256 / TPR;                     // rows per iteration
+  const int tc = (tid % TPR) * 8, tr = tid / TPR;
+  const int n = n0 + tc;
+  const bool vec = (n + 7 < g.N) && ((g.ldc & 7) == 0) && ((coff & 7) == 0);
+  float bv[8];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 16 + fr;
-    if (n >= g.N) continue;
-    const float bv = bias ? bias[n] : 0.0f;
+  for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < g.N) ? bias[n + e] : 0.f;
+#pragma unroll 2
+  for (int rr = tr; rr < BM; rr += RPI) {
+    const int m = m0 + rr;
+    if (m >= g.M || n >= g.N) continue;
+    float v[8];
+    const float4 t0 = *(const float4*)(tile + rr * LDT + tc), t1 = *(const float4*)(tile + rr * LDT + tc + 4);
+    v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], g.act);
+    const long long o = coff + (long long)m * g.ldc + n;
+    if (vec) {
+      if (res) {
+        const float* rp = res + (long long)m * g.ldr + n;
+        if ((((uintptr_t)rp) & 15) == 0) {
+          const float4 r0 = *(const float4*)rp, r1 = *(const float4*)(rp + 4);
+          v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * WM + i * 16 + fq * 4 + r;
-        if (m >= g.M) continue;
-        float v = apply_act(acc[i][j][r] + bv, g.act);
-        if (res) v += res[(long long)m * g.ldr + n];
-        const long long o = coff + (long long)m * g.ldc + n;
-        if (g.c_f32) g.c_f32[o] = v;
+          for (int e = 0; e < 8; ++e) v[e] += rp[e];
+        }
+      }
+      if (g.c_f32) {
+        *(float4*)(g.c_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(g.c_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      if (g.c_hi) {
+        uint32_t ph[4], pl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bf16_t h0, l0, h1, l1;
+          split_bf16(v[2 * e], h0, l0);
+          split_bf16(v[2 * e + 1], h1, l1);
+          ph[e] = h0 | ((uint32_t)h1 << 16);
+          pl[e] = l0 | ((uint32_t)l1 << 16);
+        }
+        *(uint4*)(g.c_hi + o) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        if (g.c_lo) *(uint4*)(g.c_lo + o) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (n + e >= g.N) break;
+        float x = v[e];
+        if (res) x += res[(long long)m * g.ldr + n + e];
+        if (g.c_f32) g.c_f32[o + e] = x;
         if (g.c_hi) {
           bf16_t h, l;
-          split_bf16(v, h, l);
-          g.c_hi[o] = h;
-          if (g.c_lo) g.c_lo[o] = l;
+          split_bf16(x, h, l);
+          g.c_hi[o + e] = h;
+          if (g.c_lo) g.c_lo[o + e] = l;
         }
       }
     }
