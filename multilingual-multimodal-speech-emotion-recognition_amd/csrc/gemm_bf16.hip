@@ -32,7 +32,8 @@ SER_DEVFN void stage_tile(const bf16_t* __restrict__ base, long long ld, int row
   const int r = lane >> 3;
   const int c = (lane & 7) ^ r;   // source chunk for LDS chunk position lane&7 of row r
 #pragma unroll
-  for (int p = wave; p < R / 8; p += 4) {
+  for (int i = 0; i < R / 32; ++i) {      // constant trip count: no scalar branches between the LDS-DMA issues
+    const int p = wave + 4 * i;
     int row = row0 + p * 8 + r;
     row = row < rmax ? row : rmax;
     const bf16_t* src = base + (long long)row * ld + k0 + c * 8;

@@ -30,11 +30,10 @@ struct SerGemmF32Args {
   int k_chunk;
   float* ws;
   float* ws_rowsum;
+  int vec_a, vec_b;   // set by the launcher: the contiguous axis of a / b is 16-byte aligned per float4 group
 };
 
 namespace {
-
-constexpr int FBK = 16;
 
 SER_DEVFN float act_f32(float v, int act) {
   switch (act) {
@@ -46,50 +45,92 @@ SER_DEVFN float act_f32(float v, int act) {
   }
 }
 
-// R = rows of the tile in its non-k dimension (BM for A, BN for B); each thread moves R*16/256 elements
-template <int R>
+// R = rows of the tile in its non-k dimension (BM for A, BN for B), KT = k extent of the tile.
+// Each thread moves R*KT/256 elements as float4 groups along the operand's contiguous axis.
+template <int R, int KT>
 struct TileRegs {
-  float v[R * FBK / 256];
+  float4 v[R * KT / 1024];
 };
 
-// element (r, k) of the operand lives at p[r*sr + k*sk]; rows r0.., k from k0
-template <int R>
-SER_DEVFN void load_tile(TileRegs<R>& t, const float* __restrict__ p, long long sr, long long sk, int r0, int rmax,
-                         int k0, int K, int tid, bool kfast) {
-  constexpr int NE = R * FBK / 256;
+// element (r, k) of the operand lives at p[r*sr + k*sk]; rows r0.. (< rmax), k from k0 (< kmax).
+// Loads are UNCONDITIONAL (out-of-range groups read offset 0 and are zeroed by a select): a branch
+// around a load makes hipcc wait vmcnt(0) at every join and serialises the whole prefetch.
+// vec: every float4 group along the contiguous axis is 16-byte aligned and entirely in or out of range.
+template <int R, int KT, bool FAST = false>
+SER_DEVFN void load_tile(TileRegs<R, KT>& t, const float* __restrict__ p, long long sr, long long sk, int r0, int rmax,
+                         int k0, int kmax, int tid, bool kfast, bool vec) {
+  constexpr int NG = R * KT / 1024;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int idx = tid * NE + e;   // consecutive elements of one thread run along the fast axis
+  for (int e = 0; e < NG; ++e) {
+    const int g = tid + 256 * e;        // float4 group index; consecutive threads walk the contiguous axis
     int r, k;
-    if (kfast) { r = idx / FBK; k = idx % FBK; } else { k = idx / R; r = idx % R; }
+    if (kfast) { r = g / (KT / 4); k = (g % (KT / 4)) * 4; } else { k = g / (R / 4); r = (g % (R / 4)) * 4; }
     const int gr = r0 + r, gk = k0 + k;
-    t.v[e] = (gr < rmax && gk < K) ? p[(long long)gr * sr + (long long)gk * sk] : 0.f;
+    const long long base = (long long)gr * sr + (long long)gk * sk;
+    const long long step = kfast ? sk : sr;          // == 1 along the contiguous axis
+    const int lim = kfast ? kmax - gk : rmax - gr;   // valid elements of this group along that axis
+    const bool ok = kfast ? gr < rmax : gk < kmax;
+    float4 v;
+    if (FAST) {
+      // no k tail (host guarantees it) and rows clamped into range: rows beyond the matrix only feed
+      // accumulators that are never stored, so no select may sit between the load and the MFMAs
+      const int cr = kfast ? min(gr, rmax - 1) : min(gr, rmax - 4);
+      v = *(const float4*)(p + (long long)cr * sr + (long long)gk * sk);
+    } else if (vec) {
+      const bool in = ok && lim >= 4;
+      v = *(const float4*)(p + (in ? base : 0));
+      if (!in) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const float x0 = p[(ok && lim > 0) ? base : 0];
+      const float x1 = p[(ok && lim > 1) ? base + step : 0];
+      const float x2 = p[(ok && lim > 2) ? base + 2 * step : 0];
+      const float x3 = p[(ok && lim > 3) ? base + 3 * step : 0];
+      v.x = (ok && lim > 0) ? x0 : 0.f;
+      v.y = (ok && lim > 1) ? x1 : 0.f;
+      v.z = (ok && lim > 2) ? x2 : 0.f;
+      v.w = (ok && lim > 3) ? x3 : 0.f;
+    }
+    t.v[e] = v;
   }
 }
 
-template <int R, int LD>
-SER_DEVFN void store_tile(const TileRegs<R>& t, float* s, int tid, bool kfast) {
-  constexpr int NE = R * FBK / 256;
+// LDS image of a tile: k-fast operands are kept [row][k] with pitch KT+2 (fragment read = 16 rows x 2 k
+// per half-wave -> banks 2*row + k: conflict-free), row-fast operands [k][row] with pitch R+16.
+template <int R, int KT, int LD>
+SER_DEVFN void store_tile(const TileRegs<R, KT>& t, float* s, int tid, bool kfast) {
+  constexpr int NG = R * KT / 1024;
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
-    const int idx = tid * NE + e;
-    int r, k;
-    if (kfast) { r = idx / FBK; k = idx % FBK; } else { k = idx / R; r = idx % R; }
-    s[k * LD + r] = t.v[e];
+  for (int e = 0; e < NG; ++e) {
+    const int g = tid + 256 * e;
+    if (kfast) {
+      const int r = g / (KT / 4), k = (g % (KT / 4)) * 4;
+      float2* d = (float2*)(s + r * (KT + 2) + k);     // pitch KT+2 floats: 8-byte aligned, not 16
+      d[0] = make_float2(t.v[e].x, t.v[e].y);
+      d[1] = make_float2(t.v[e].z, t.v[e].w);
+    } else {
+      const int k = g / (R / 4), r = (g % (R / 4)) * 4;
+      *(float4*)(s + k * LD + r) = t.v[e];
+    }
   }
 }
 
-template <int BM, int BN>
+// AKF / BKF: 1 = operand is k-contiguous, 0 = row-contiguous, 2 = decide at run time; VEC likewise.
+// Compile-time layouts matter: with run-time selects hipcc branches around the loads and drains vmcnt(0)
+// at every join, which serialises the register prefetch.
+template <int BM, int BN, int FBK, int AKF = 2, int BKF = 2, int VEC = 2>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const SerGemmF32Args g) {
-  constexpr int LDA = BM == 64 ? 80 : 16, LDB = BN == 64 ? 80 : 16;   // (LD % 32) == 16: two k-rows per half-wave, no conflict
+  constexpr int LDA = BM == 64 ? 80 : 16, LDB = BN == 64 ? 80 : 16;   // row-fast pitch, (LD % 32) == 16: no conflict
+  constexpr int LDK = FBK + 2;                                          // k-fast pitch
+  constexpr int ASZ = (BM * LDK > FBK * LDA) ? BM * LDK : FBK * LDA;
+  constexpr int BSZ = (BN * LDK > FBK * LDB) ? BN * LDK : FBK * LDB;
   constexpr int WAVES_M = BN == 16 ? 4 : (BM == 64 ? 2 : 1), WAVES_N = 4 / WAVES_M;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 16, TN = WN / 16;
-  __shared__ float As[2][FBK * LDA];
-  __shared__ float Bs[2][FBK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][ASZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BSZ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const bool a_kfast = g.sak == 1, b_kfast = g.sbk == 1;
+  const bool a_kfast = AKF == 2 ? g.sak == 1 : AKF == 1, b_kfast = BKF == 2 ? g.sbk == 1 : BKF == 1;
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -97,44 +138,51 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const SerGemmF32Args g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TileRegs<BM> ra;
-  TileRegs<BN> rb;
+  TileRegs<BM, FBK> ra;
+  TileRegs<BN, FBK> rb;
+  const bool avec = VEC == 2 ? g.vec_a != 0 : VEC == 1, bvec = VEC == 2 ? g.vec_b != 0 : VEC == 1;
   const int kbeg = g.k_chunk ? blockIdx.z * g.k_chunk : 0;
   const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
   const int nk = (kend - kbeg + FBK - 1) / FBK;
   float rowsum = 0.f;
   const bool want_rowsum = g.ws_rowsum != nullptr && blockIdx.x == 0 && tid < BM;
-  load_tile<BM>(ra, g.a, g.sam, g.sak, m0, g.M, kbeg, kend, tid, a_kfast);
-  load_tile<BN>(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid, b_kfast);
-  store_tile<BM, LDA>(ra, As[0], tid, a_kfast);
-  store_tile<BN, LDB>(rb, Bs[0], tid, b_kfast);
+  load_tile<BM, FBK, VEC == 1>(ra, g.a, g.sam, g.sak, m0, g.M, kbeg, kend, tid, a_kfast, avec);
+  load_tile<BN, FBK, VEC == 1>(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid, b_kfast, bvec);
+  store_tile<BM, FBK, LDA>(ra, As[0], tid, a_kfast);
+  store_tile<BN, FBK, LDB>(rb, Bs[0], tid, b_kfast);
   __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-      load_tile<BM>(ra, g.a, g.sam, g.sak, m0, g.M, kbeg + (kt + 1) * FBK, kend, tid, a_kfast);
-      load_tile<BN>(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg + (kt + 1) * FBK, kend, tid, b_kfast);
+      load_tile<BM, FBK, VEC == 1>(ra, g.a, g.sam, g.sak, m0, g.M, kbeg + (kt + 1) * FBK, kend, tid, a_kfast, avec);
+      load_tile<BN, FBK, VEC == 1>(rb, g.b, g.sbn, g.sbk, n0, g.N, kbeg + (kt + 1) * FBK, kend, tid, b_kfast, bvec);
     }
     if (want_rowsum) {
 #pragma unroll
-      for (int kk = 0; kk < FBK; ++kk) rowsum += As[cur][kk * LDA + tid];
+      for (int kk = 0; kk < FBK; ++kk) rowsum += a_kfast ? As[cur][tid * LDK + kk] : As[cur][kk * LDA + tid];
     }
 #pragma unroll
     for (int ks = 0; ks < FBK / 4; ++ks) {
       float af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = As[cur][(ks * 4 + fq) * LDA + wm * WM + i * 16 + fr];
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + i * 16 + fr, k = ks * 4 + fq;
+        af[i] = a_kfast ? As[cur][row * LDK + k] : As[cur][k * LDA + row];
+      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = Bs[cur][(ks * 4 + fq) * LDB + wn * WN + j * 16 + fr];
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + j * 16 + fr, k = ks * 4 + fq;
+        bf[j] = b_kfast ? Bs[cur][row * LDK + k] : Bs[cur][k * LDB + row];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) {
-      store_tile<BM, LDA>(ra, As[cur ^ 1], tid, a_kfast);
-      store_tile<BN, LDB>(rb, Bs[cur ^ 1], tid, b_kfast);
+      store_tile<BM, FBK, LDA>(ra, As[cur ^ 1], tid, a_kfast);
+      store_tile<BN, FBK, LDB>(rb, Bs[cur ^ 1], tid, b_kfast);
     }
     __syncthreads();
   }
@@ -357,23 +405,57 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
 
 }  // namespace
 
-int ser_launch_gemm_f32(const SerGemmF32Args& g, hipStream_t st) {
+static int g_f32_bk = 0;   // 0 = automatic
+static int g_f32_bk_fwd() { return g_f32_bk; }
+extern "C" int ser_debug_set_f32_bk(int bk) { g_f32_bk = bk; return 0; }
+template <int FBK>
+static void launch_6464_bk(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
+  dim3 block(256);
+  const int kext = g.k_chunk ? g.k_chunk : g.K;
+  const bool notail = (g.K % FBK) == 0 && (kext % FBK) == 0 && g.M >= 4 && g.N >= 4;
+  const bool ak = g.sak == 1, bk = g.sbk == 1, v = g.vec_a && g.vec_b && notail;
+  if (v && ak && bk) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, FBK, 1, 1, 1>), grid, block, 0, st, g);       // y = x W^T
+  else if (v && ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, FBK, 1, 0, 1>), grid, block, 0, st, g); // dx = dy W
+  else if (v && !ak && !bk) hipLaunchKernelGGL((gemm_f32_kernel<64, 64, FBK, 0, 0, 1>), grid, block, 0, st, g); // dW = dy^T x
+  else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, FBK, 2, 2, 2>), grid, block, 0, st, g);
+}
+static int g_f32_bk_fwd();
+static void launch_6464(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
+  // measured on MI355X (scripts/gemm_f32_bench.py): split-K grids (many resident workgroups) are fastest at
+  // BK 16, single-pass grids (<= a few hundred workgroups, latency hidden inside the workgroup) at BK 32
+  const int bk = g_f32_bk_fwd() ? g_f32_bk_fwd() : (g.k_chunk ? 16 : 32);
+  if (bk == 16) launch_6464_bk<16>(g, grid, st);
+  else if (bk == 32) launch_6464_bk<32>(g, grid, st);
+  else launch_6464_bk<64>(g, grid, st);
+}
+
+// float4 groups along an operand's contiguous axis are usable when the base and the other stride keep them
+// 16-byte aligned and the extent along that axis is a multiple of 4 (a group is then all-in or all-out)
+static bool vec_ok(const float* p, long long s_fast, long long s_slow, int extent) {
+  return s_fast == 1 && (s_slow % 4) == 0 && (extent % 4) == 0 && (((uintptr_t)p) & 15) == 0;
+}
+
+int ser_launch_gemm_f32(const SerGemmF32Args& gin, hipStream_t st) {
+  SerGemmF32Args g = gin;
   SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
   SER_REQUIRE(g.a && g.b && g.c, "gemm_f32: null operand");
+  g.vec_a = (g.sak == 1 ? vec_ok(g.a, g.sak, g.sam, g.K) : vec_ok(g.a, g.sam, g.sak, g.M)) ? 1 : 0;
+  g.vec_b = (g.sbk == 1 ? vec_ok(g.b, g.sbk, g.sbn, g.K) : vec_ok(g.b, g.sbn, g.sbk, g.N)) ? 1 : 0;
+  if (g.k_chunk) SER_REQUIRE(g.k_chunk % 4 == 0, "gemm_f32: k_chunk must be a multiple of 4");
   dim3 block(256);
   const int zs = g.k_chunk ? ceil_div(g.K, g.k_chunk) : 1;
   if (g.k_chunk) {
     dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64), zs);
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, block, 0, st, g);
+    launch_6464(g, grid, st);
   } else if (g.M <= 16) {
     dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 16));
-    hipLaunchKernelGGL((gemm_f32_kernel<16, 64>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<16, 64, 64>), grid, block, 0, st, g);
   } else if (g.N <= 16) {
     dim3 grid(ceil_div(g.N, 16), ceil_div(g.M, 64));
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 16>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_f32_kernel<64, 16, 64>), grid, block, 0, st, g);
   } else {
     dim3 grid(ceil_div(g.N, 64), ceil_div(g.M, 64));
-    hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, block, 0, st, g);
+    launch_6464(g, grid, st);
   }
   SER_LAUNCH_CHECK();
   return SER_OK;
@@ -386,7 +468,7 @@ extern "C" int ser_gemm_f32(const float* a, long long sam, long long sak, const 
   g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr; g.accumulate = accumulate;
-  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr;
+  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0;
   return ser_launch_gemm_f32(g, (hipStream_t)stream);
 }
 
@@ -448,7 +530,7 @@ extern "C" int ser_linear_wgrad(const float* dy, const float* x, float* dW, floa
   g.a = dy; g.b = x; g.c = dW; g.M = N; g.N = K; g.K = M;
   g.sam = 1; g.sak = N; g.sbk = K; g.sbn = 1; g.ldc = K;
   g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = accumulate;
-  g.k_chunk = chunk;
+  g.k_chunk = chunk; g.vec_a = g.vec_b = 0;
   g.ws = (float*)workspace;
   g.ws_rowsum = db ? g.ws + (size_t)splits * N * K : nullptr;
   SER_TRY(ser_launch_gemm_f32(g, st));
