@@ -1,0 +1,166 @@
+"""CPU-only tests of the host-side logic around the kernels: flat parameter buckets, optimizer
+planning and schedule, state_dict key parity with the reference, CLI flags, data-feed helpers."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_npz
+
+import ser_amd  # noqa: F401
+
+
+def _manifest():
+    return json.load(open(os.path.join(GOLDEN, "state_dict_manifest.json")))
+
+
+def test_state_dict_keys_match_reference_full_size():
+    from ser_amd.models import FusionLayer
+    from ser_amd.models.classifier import AdvancedOpenMaxClassifier
+    from ser_amd.models.cross_attention import CrossModalAttention
+    from ser_amd.models.pooling import AttentiveStatsPooling
+    from ser_amd.models.prototypes import PrototypeMemory
+    man = _manifest()
+    shapes = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert shapes(AdvancedOpenMaxClassifier(512, 4, 35, 512, 0.15)) == man["classifier"]
+    assert shapes(CrossModalAttention(768, 768, 256, 8)) == man["cross"]
+    assert shapes(FusionLayer(1536, 1536, 512)) == man["fusion"]
+    assert shapes(AttentiveStatsPooling(768)) == man["pool"]
+    assert shapes(PrototypeMemory(4, 512)) == man["prototypes"]
+
+
+def test_encoder_wrappers_keep_reference_keys():
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    from ser_amd.models import AudioEncoder, TextEncoder
+    man = _manifest()
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                        conv_dim=[64] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    ae = AudioEncoder(hf_config=wc, adapter_dim=32, use_quality_gates=False, use_audio_conditioning=False)
+    assert {k: list(v.shape) for k, v in ae.state_dict().items()} == man["audio_encoder_small"]
+    xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                          intermediate_size=256, max_position_embeddings=66, type_vocab_size=1, pad_token_id=1)
+    te = TextEncoder(hf_config=xc, adapter_dim=32)
+    assert {k: list(v.shape) for k, v in te.state_dict().items()} == man["text_encoder_small"]
+    # with the gate flags on, the reference's extra learnable keys exist too
+    ae2 = AudioEncoder(hf_config=wc, adapter_dim=32)
+    keys = set(ae2.state_dict())
+    for k in ("quality_gates.quality_projection.0.weight", "quality_gates.quality_projection.3.bias", "quality_fusion.0.weight",
+              "audio_conditioning.conditioning_projection.0.weight", "conditioning_fusion.0.weight", "combined_fusion.0.weight"):
+        assert k in keys
+    assert ae2.state_dict()["combined_fusion.0.weight"].shape == (128, 148)
+    with pytest.raises(NotImplementedError):
+        ae2([torch.zeros(4000)])
+
+
+def test_flat_params_views_roundtrip_and_reflatten():
+    from ser_amd.models import FusionLayer
+    m = FusionLayer(32, 32, 16)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fp = m._flat.ensure()
+    assert fp.flat.numel() == fp.total and fp.total % 64 == 0
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    for p, o in zip(fp.params, fp.offsets):
+        assert p.data_ptr() == fp.flat.data_ptr() + 4 * o and o % 64 == 0
+    # load_state_dict writes through the views
+    sd = {k: torch.randn_like(v) for k, v in before.items()}
+    m.load_state_dict(sd)
+    assert torch.equal(fp.flat[fp.offsets[0]:fp.offsets[0] + fp.params[0].numel()].view_as(fp.params[0]), sd["proj_a.0.weight"])
+    # a dtype/device move re-points the parameters: ensure() must notice and re-flatten
+    m.double().float()
+    fp2 = m._flat.ensure()
+    assert fp2.params[0].data_ptr() == fp2.flat.data_ptr()
+    assert not fp.accumulating()
+    fp.publish()
+    assert fp.accumulating()
+
+
+def test_optimizer_plan_follows_reference_groups():
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    from ser_amd.models import AudioEncoder, TextEncoder
+    from ser_amd.system import SERSystem
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                        conv_dim=[64] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    xc = XLMRobertaConfig(vocab_size=100, hidden_size=128, num_hidden_layers=1, num_attention_heads=2,
+                          intermediate_size=128, max_position_embeddings=40, type_vocab_size=1, pad_token_id=1)
+    s = SERSystem(AudioEncoder(hf_config=wc, adapter_dim=16, use_quality_gates=False, use_audio_conditioning=False),
+                  TextEncoder(hf_config=xc, adapter_dim=16), num_labels=4, shared_dim=64, num_heads=2, proj_dim=64,
+                  num_layers=2, base_dim=64)
+    from ser_amd.models.adapter import adapter_apply  # buckets for the adapters are created lazily
+    from ser_amd.models._flat import FlatParams
+    for enc in (s.audio_encoder, s.text_encoder):
+        enc._adapter_flat = FlatParams(list(enc.adapter.parameters()))
+    opt = s.make_optimizer(lr=1e-3)
+    opt._build_plan()
+    mults = [round(g["lr_mult"], 6) for g, _, _ in opt._plan]
+    wds = [g["weight_decay"] for g, _, _ in opt._plan]
+    assert mults == [0.1, 0.1, 1, 1, 1, 1, 1.5, 2.0, 1.0, 1]            # ref train.py:72-83
+    assert wds == [.025, .025, .05, .05, .05, .05, .06, .04, .05, .05]
+    # the classifier's three groups are three contiguous, disjoint segments of ONE flat bucket
+    segs = [opt._plan[i][1] for i in (6, 7, 8)]
+    assert all(len(x) == 1 for x in segs) and len({id(x[0][0]) for x in segs}) == 1
+    (b, s0, e0), (_, s1, e1), (_, s2, e2) = segs[0][0], segs[1][0], segs[2][0]
+    assert s0 == 0 and e0 == s1 and e1 == s2 and e2 == b.total
+    # frozen encoder weights are not planned; the adapter bucket is; the encoder's unused `pool` head is planned
+    # but, exactly like torch (grad is None -> skipped), never updated because it never receives a gradient
+    audio_segs = opt._plan[0][1]
+    assert audio_segs[0][0] is s.audio_encoder._adapter_flat
+    assert [sg[0] for sg in audio_segs[1:]] == [s.audio_encoder.pool._flat]
+    assert all(p.grad is None for p in s.audio_encoder.pool.parameters())
+    assert opt._plan[9][2] == [s.prototypes.prototypes]
+
+
+def test_warmup_cosine_matches_reference_lambda():
+    from ser_amd.optim import WarmupCosine
+
+    class _Opt:
+        lr_factor = 1.0
+    r = load_npz("adamw.npz")
+    o = _Opt()
+    sch = WarmupCosine(o, int(r["total_steps"]), float(r["warmup_ratio"]))
+    got = [o.lr_factor]
+    for _ in range(int(r["total_steps"])):
+        sch.step()
+        got.append(o.lr_factor)
+    np.testing.assert_allclose(got, r["lambda_values"], atol=1e-7)
+    assert got[0] == 0.0     # like torch's LambdaLR, the first optimizer step runs with lr * lambda(0) = 0
+
+
+def test_cli_flags_match_reference():
+    from ser_amd.train import build_parser
+    a = build_parser().parse_args([])
+    ref_defaults = dict(train_manifest='train_70.jsonl', val_manifest='val_20.jsonl', epochs=5, batch_size=4, lr=1e-4,
+                        warmup_ratio=0.1, use_amp=False, augment=False, proto_weight=0.05, save_dir='checkpoints',
+                        resume_from=None)
+    for k, v in ref_defaults.items():
+        assert getattr(a, k) == v, k
+
+
+def test_checkpoint_layout_keys():
+    from ser_amd.system import SERSystem
+    assert SERSystem.CKPT_KEYS == ("audio_encoder", "text_encoder", "cross", "pool_a", "pool_t", "fusion", "classifier",
+                                   "prototypes")     # ref train.py:249-262 (+ optimizer, scheduler, epoch, f1)
+
+
+def test_speed_perturb_is_length_preserving_lowpass():
+    from ser_amd.data.preprocess import add_noise_snr, resample, speed_perturb
+    t = torch.arange(16000) / 16000.0
+    tone = 0.5 * torch.sin(2 * np.pi * 440 * t)
+    for f in (0.9, 0.95, 1.05, 1.1):
+        y = speed_perturb(tone, f)
+        assert y.shape == tone.shape                       # ref preprocess.py:56-61: duration does not change
+        assert (y[200:-200] - tone[200:-200]).abs().max() < 2e-2   # a 440 Hz tone survives the round trip
+    assert speed_perturb(tone, 1.0005) is tone
+    assert resample(tone[None], 16000, 8000).shape == (1, 8000)
+    n = add_noise_snr(tone, 10.0)
+    snr = 10 * torch.log10(tone.pow(2).mean() / (n - tone).pow(2).mean())
+    assert abs(float(snr) - 10.0) < 0.5 and float(n.abs().max()) <= 1.0
+
+
+def test_synthetic_dataset_shapes():
+    from ser_amd.data.dataset import SyntheticSERDataset
+    ds = SyntheticSERDataset(5, seconds=1.0, num_labels=4)
+    w, txt, y = ds[3]
+    assert w.shape == (16000,) and len(txt.split()) == 30 and 0 <= y < 4
