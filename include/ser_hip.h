@@ -170,7 +170,14 @@ int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, l
  * folds the bias gradient (column sums of dy) into the same pass. */
 int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
                    float* y, int M, int N, int K, void* stream);
-int ser_linear_dgrad(const float* dy, const float* W, float* dx, int M, int N, int K, int accumulate, void* stream);
+/* relu_mask (may be NULL): the ReLU OUTPUT of the layer that produced x; when given, dx is multiplied by
+ * relu'(mask), i.e. the activation backward is fused into the dgrad epilogue. */
+int ser_linear_dgrad(const float* dy, const float* W, const float* relu_mask, float* dx, int M, int N, int K,
+                     int accumulate, void* stream);
+/* two weight gradients of a classifier block (M <= 16) in one launch */
+int ser_linear_wgrad_pair(const float* dya, const float* xa, float* dWa, float* dba, int Na, int Ka,
+                          const float* dyb, const float* xb, float* dWb, float* dbb, int Nb, int Kb, int M,
+                          int accumulate, void* stream);
 size_t ser_linear_wgrad_workspace_bytes(int M, int N, int K);
 int ser_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int M, int N, int K, int accumulate,
                      void* workspace, size_t workspace_bytes, void* stream);
@@ -183,6 +190,14 @@ int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const 
                       const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
                       float* dbeta, int accumulate_params, void* stream);
 
+/* the two chained LayerNorms of a classifier block (classifier.py:209-210) fused: forward keeps
+ * stats[4][rows] = mean1, rstd1, mean2, rstd2; backward returns dx = LN1'(LN2'(du) + dres) and all four
+ * parameter gradients from one single-workgroup launch (rows = batch). */
+int ser_layernorm2_fwd(const float* x, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
+                       int rows, int D, float* y1, float* y2, float* stats, void* stream);
+int ser_layernorm2_bwd(const float* du, const float* dres, const float* x, const float* y1, const float* stats,
+                       const float* g1, const float* g2, int rows, int D, float* dx, float* dg1, float* db1,
+                       float* dg2, float* db2, int accumulate, void* stream);
 int ser_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
 int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream);
 int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);

@@ -25,13 +25,45 @@ def linear_fwd(x, W, b=None, act=ACT_NONE, residual=None, out=None):
     return y
 
 
-def linear_dgrad(dy, W, out=None, accumulate=False):
-    """dx[M,K] (+)= dy[M,N] W[N,K]."""
+def linear_dgrad(dy, W, out=None, accumulate=False, relu_mask=None):
+    """dx[M,K] (+)= (dy[M,N] W[N,K]) * relu'(relu_mask)."""
     M, N = dy.shape
     K = W.shape[1]
     dx = out if out is not None else empty(M, K, like=dy)
-    L.check(L.lib.ser_linear_dgrad(L.ptr(dy), L.ptr(W), L.ptr(dx), M, N, K, 1 if accumulate else 0, L.stream_ptr()),
-            "ser_linear_dgrad")
+    L.check(L.lib.ser_linear_dgrad(L.ptr(dy), L.ptr(W), L.ptr(relu_mask), L.ptr(dx), M, N, K, 1 if accumulate else 0,
+                                   L.stream_ptr()), "ser_linear_dgrad")
+    return dx
+
+
+def linear_wgrad_pair(dya, xa, dWa, dba, dyb, xb, dWb, dbb, accumulate=False):
+    """Two skinny (M <= 16) weight gradients + bias gradients in one launch."""
+    M = dya.shape[0]
+    if M > 16:
+        linear_wgrad(dya, xa, dWa, dba, accumulate)
+        linear_wgrad(dyb, xb, dWb, dbb, accumulate)
+        return
+    L.check(L.lib.ser_linear_wgrad_pair(L.ptr(dya), L.ptr(xa), L.ptr(dWa), L.ptr(dba), dya.shape[1], xa.shape[1], L.ptr(dyb),
+                                        L.ptr(xb), L.ptr(dWb), L.ptr(dbb), dyb.shape[1], xb.shape[1], M,
+                                        1 if accumulate else 0, L.stream_ptr()), "ser_linear_wgrad_pair")
+
+
+def ln2_fwd(x, g1, b1, g2, b2, eps=1e-5):
+    """y1 = LN(x; g1,b1), y2 = LN(y1; g2,b2) in one launch -> y1, y2, stats[4, rows]."""
+    rows, D = x.shape
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    stats = empty(4, rows, like=x)
+    L.check(L.lib.ser_layernorm2_fwd(L.ptr(x), L.ptr(g1), L.ptr(b1), L.ptr(g2), L.ptr(b2), eps, rows, D, L.ptr(y1), L.ptr(y2),
+                                     L.ptr(stats), L.stream_ptr()), "ser_layernorm2_fwd")
+    return y1, y2, stats
+
+
+def ln2_bwd(du, dres, x, y1, stats, g1, g2, dg1, db1, dg2, db2, accumulate=False):
+    """dx = LN1'(LN2'(du) + dres) and the four parameter gradients in one launch."""
+    rows, D = du.shape
+    dx = torch.empty_like(du)
+    L.check(L.lib.ser_layernorm2_bwd(L.ptr(du), L.ptr(dres), L.ptr(x), L.ptr(y1), L.ptr(stats), L.ptr(g1), L.ptr(g2), rows, D,
+                                     L.ptr(dx), L.ptr(dg1), L.ptr(db1), L.ptr(dg2), L.ptr(db2), 1 if accumulate else 0,
+                                     L.stream_ptr()), "ser_layernorm2_bwd")
     return dx
 
 

@@ -247,14 +247,14 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fwd_kernel(const float* __r
   for (int it = 0; it < nit; it += 4) {               // 8 x 16-B loads in flight per lane before the MFMAs
     float4 a[4], b[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = w + (it + u) * WAVES;
-      const bool ok = it + u < nit;
-      a[u] = ok ? *(const float4*)(xr + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
-      b[u] = ok ? *(const float4*)(wr + c * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 4; ++u) {                     // unconditional loads from a clamped chunk (no branch, no early wait)
+      const int c = min(w + (it + u) * WAVES, nchunk - 1);
+      a[u] = *(const float4*)(xr + c * 16);
+      b[u] = *(const float4*)(wr + c * 16);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
+      if (it + u >= nit) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
@@ -283,9 +283,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fwd_kernel(const float* __r
   }
 }
 
-// dx[M,Kc] = dy[M,N] . W[N,Kc]   (reduction over N split across the waves)
+// dx[M,Kc] = (dy[M,N] . W[N,Kc]) * relu'(mask)   (reduction over N split across the waves; mask = the
+// ReLU OUTPUT of the layer below, or NULL: fuses the activation backward into the dgrad epilogue)
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                                  const float* __restrict__ relu_mask,
                                                                   float* __restrict__ dx, int M, int N, int Kc,
                                                                   int accumulate) {
   __shared__ float red[WAVES][64][16];
@@ -293,28 +295,30 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_dgrad_kernel(const float* _
   const int i = lane & 15, q = lane >> 4;
   const int c0 = blockIdx.x * 64 + 4 * i;
   const bool cok = c0 < Kc;
+  const int cc = cok ? c0 : 0;                       // clamped column group: loads stay unconditional
   const float* dyr = dy + (long long)min(i, M - 1) * N;
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nsteps = (N + 3) >> 2;
   const int nit = (nsteps - w + WAVES - 1) / WAVES;
-  for (int it = 0; it < nit; it += 4) {
-    float a[4];
-    float4 b[4];
+  for (int it = 0; it < nit; it += 8) {              // 8 weight rows (16 B per lane each) in flight per lane
+    float a[8];
+    float4 b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int n = (w + (it + u) * WAVES) * 4 + q;
-      const bool ok = it + u < nit && n < N;
-      a[u] = ok ? dyr[n] : 0.f;
-      b[u] = (ok && cok) ? *(const float4*)(W + (long long)n * Kc + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 8; ++u) {
+      const int n = min((w + (it + u) * WAVES) * 4 + q, N - 1);
+      a[u] = dyr[n];
+      b[u] = *(const float4*)(W + (long long)n * Kc + cc);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].x, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].y, acc[1], 0, 0, 0);
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].z, acc[2], 0, 0, 0);
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u].w, acc[3], 0, 0, 0);
+    for (int u = 0; u < 8; ++u) {
+      const int n = (w + (it + u) * WAVES) * 4 + q;
+      const float av = (it + u < nit && n < N) ? a[u] : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u].z, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u].w, acc[3], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -334,8 +338,12 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_dgrad_kernel(const float* _
 #pragma unroll
         for (int ww = 0; ww < WAVES; ++ww) v[t] += red[ww][lane][t * 4 + r];
       }
-      float4* dst = (float4*)(dx + (long long)m * Kc + c0);
       float4 o = make_float4(v[0], v[1], v[2], v[3]);
+      if (relu_mask) {
+        const float4 mk = *(const float4*)(relu_mask + (long long)m * Kc + c0);
+        o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f;
+      }
+      float4* dst = (float4*)(dx + (long long)m * Kc + c0);
       if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
       *dst = o;
     }
@@ -343,9 +351,21 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_dgrad_kernel(const float* _
 }
 
 // dW[N,Kc] (+)= dy[M<=16,N]^T . x[M,Kc] ; db[N] (+)= sum_m dy[m,n]
-__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           float* __restrict__ dW, float* __restrict__ db, int M, int N,
-                                                           int Kc, int accumulate) {
+struct SkinnyWgradArgs {
+  const float *dy, *x;
+  float *dW, *db;
+  int N, Kc;
+};
+
+__global__ __launch_bounds__(256) void skinny_wgrad_kernel(const SkinnyWgradArgs p0, const SkinnyWgradArgs p1, int M,
+                                                           int accumulate) {
+  const SkinnyWgradArgs& P = blockIdx.z == 0 ? p0 : p1;   // up to two independent problems per launch
+  const float* __restrict__ dy = P.dy;
+  const float* __restrict__ x = P.x;
+  float* __restrict__ dW = P.dW;
+  float* __restrict__ db = P.db;
+  const int N = P.N, Kc = P.Kc;
+  if ((int)blockIdx.y * 64 >= N || (int)blockIdx.x * 64 >= Kc) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.y * 64 + w * 16;
@@ -491,19 +511,39 @@ extern "C" int ser_linear_fwd(const float* x, const float* W, const float* bias,
 }
 
 // dx[M,K] (+)= dy[M,N] W[N,K]
-extern "C" int ser_linear_dgrad(const float* dy, const float* W, float* dx, int M, int N, int K, int accumulate,
-                                void* stream) {
+extern "C" int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);
+
+extern "C" int ser_linear_dgrad(const float* dy, const float* W, const float* relu_mask, float* dx, int M, int N, int K,
+                                int accumulate, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (M <= 16 && K % 4 == 0 && aligned16(W) && aligned16(dx)) {
     SER_REQUIRE(M > 0 && N > 0 && K > 0, "linear_dgrad: empty problem");
     if (N >= 128)
-      hipLaunchKernelGGL(skinny_dgrad_kernel<8>, dim3(ceil_div(K, 64)), dim3(512), 0, st, dy, W, dx, M, N, K, accumulate);
+      hipLaunchKernelGGL(skinny_dgrad_kernel<8>, dim3(ceil_div(K, 64)), dim3(512), 0, st, dy, W, relu_mask, dx, M, N, K, accumulate);
     else
-      hipLaunchKernelGGL(skinny_dgrad_kernel<2>, dim3(ceil_div(K, 64)), dim3(128), 0, st, dy, W, dx, M, N, K, accumulate);
+      hipLaunchKernelGGL(skinny_dgrad_kernel<2>, dim3(ceil_div(K, 64)), dim3(128), 0, st, dy, W, relu_mask, dx, M, N, K, accumulate);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
-  return ser_gemm_f32(dy, N, 1, W, K, 1, M, K, N, nullptr, SER_ACT_NONE, nullptr, 0, dx, K, accumulate, stream);
+  SER_TRY(ser_gemm_f32(dy, N, 1, W, K, 1, M, K, N, nullptr, SER_ACT_NONE, nullptr, 0, dx, K, accumulate, stream));
+  if (relu_mask) {
+    SER_REQUIRE(!accumulate, "linear_dgrad: relu_mask with accumulate needs the skinny path");
+    return ser_act_bwd(dx, relu_mask, SER_ACT_RELU, (long long)M * K, dx, stream);
+  }
+  return SER_OK;
+}
+
+// two skinny weight gradients (M <= 16) in one launch: dWa (+)= dya^T xa, dWb (+)= dyb^T xb, with their bias gradients
+extern "C" int ser_linear_wgrad_pair(const float* dya, const float* xa, float* dWa, float* dba, int Na, int Ka,
+                                     const float* dyb, const float* xb, float* dWb, float* dbb, int Nb, int Kb, int M,
+                                     int accumulate, void* stream) {
+  SER_REQUIRE(M > 0 && M <= 16 && Ka % 4 == 0 && Kb % 4 == 0, "linear_wgrad_pair: needs M <= 16 and K %% 4 == 0");
+  SER_REQUIRE(aligned16(xa) && aligned16(xb) && aligned16(dWa) && aligned16(dWb), "linear_wgrad_pair: unaligned operand");
+  SkinnyWgradArgs a{dya, xa, dWa, dba, Na, Ka}, b{dyb, xb, dWb, dbb, Nb, Kb};
+  const int gx = ceil_div(Ka > Kb ? Ka : Kb, 64), gy = ceil_div(Na > Nb ? Na : Nb, 64);
+  hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(gx, gy, 2), dim3(256), 0, (hipStream_t)stream, a, b, M, accumulate);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
 }
 
 extern "C" size_t ser_linear_wgrad_workspace_bytes(int M, int N, int K) {
@@ -518,8 +558,8 @@ extern "C" int ser_linear_wgrad(const float* dy, const float* x, float* dW, floa
   hipStream_t st = (hipStream_t)stream;
   SER_REQUIRE(M > 0 && N > 0 && K > 0, "linear_wgrad: empty problem");
   if (M <= 16 && K % 4 == 0 && aligned16(x) && aligned16(dW)) {
-    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(ceil_div(K, 64), ceil_div(N, 64)), dim3(256), 0, st, dy, x, dW, db, M, N, K,
-                       accumulate);
+    SkinnyWgradArgs a{dy, x, dW, db, N, K};
+    hipLaunchKernelGGL(skinny_wgrad_kernel, dim3(ceil_div(K, 64), ceil_div(N, 64), 1), dim3(256), 0, st, a, a, M, accumulate);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }

@@ -111,6 +111,167 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Two chained LayerNorms of a classifier block (ref classifier.py:209-210: x1 = LN_out(x); u = LN_in(x1))
+// in one launch, and their joint backward including all four parameter gradients.
+// ------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void ln2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g1,
+                                                      const float* __restrict__ b1, const float* __restrict__ g2,
+                                                      const float* __restrict__ b2, float eps, int rows, int D,
+                                                      float* __restrict__ y1, float* __restrict__ y2,
+                                                      float* __restrict__ stats /* [4][rows]: mean1,rstd1,mean2,rstd2 */) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = D >> 2;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < nchunk ? *(const float4*)(x + (long long)row * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const float* gm_p = pass == 0 ? g1 : g2;
+    const float* bt_p = pass == 0 ? b1 : b2;
+    float* yo = pass == 0 ? y1 : y2;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+      stats[(2 * pass) * rows + row] = mean;
+      stats[(2 * pass + 1) * rows + row] = rstd;
+    }
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const float4 gm = *(const float4*)(gm_p + c * 4), bt = *(const float4*)(bt_p + c * 4);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+        o.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+        o.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+        o.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        *(float4*)(yo + (long long)row * D + c * 4) = o;
+        v[i] = o;
+        s += (o.x + o.y) + (o.z + o.w);
+      }
+    }
+  }
+}
+
+// du = grad wrt y2, dres = extra grad arriving at y1 (the residual branch).  dx = LN1'(LN2'(du) + dres).
+// One workgroup walks all rows (rows = batch, small): wave w takes rows w, w+4, ...; the parameter gradients
+// are accumulated per lane over the wave's rows and reduced across the four waves through LDS.
+template <int NV>
+__global__ __launch_bounds__(256) void ln2_bwd_kernel(const float* __restrict__ du, const float* __restrict__ dres,
+                                                      const float* __restrict__ x, const float* __restrict__ y1,
+                                                      const float* __restrict__ stats, const float* __restrict__ g1,
+                                                      const float* __restrict__ g2, int rows, int D,
+                                                      float* __restrict__ dx, float* __restrict__ dg1,
+                                                      float* __restrict__ db1, float* __restrict__ dg2,
+                                                      float* __restrict__ db2, int accumulate) {
+  __shared__ float4 red[4][4][NV * 64];    // [wave][which param][chunk]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  float4 ag1[NV], ab1[NV], ag2[NV], ab2[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ag1[i] = ab1[i] = ag2[i] = ab2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row = w; row < rows; row += 4) {
+    const float m1 = stats[row], r1 = stats[rows + row], m2 = stats[2 * rows + row], r2 = stats[3 * rows + row];
+    float4 xh[NV], dgv[NV];
+    float s1 = 0.f, s2 = 0.f;
+    // ---- LN2 backward: input y1, upstream du
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        const float4 zz = *(const float4*)(y1 + (long long)row * D + c * 4);
+        const float4 d = *(const float4*)(du + (long long)row * D + c * 4);
+        const float4 gm = *(const float4*)(g2 + c * 4);
+        xh[i] = make_float4((zz.x - m2) * r2, (zz.y - m2) * r2, (zz.z - m2) * r2, (zz.w - m2) * r2);
+        dgv[i] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+        ag2[i].x += d.x * xh[i].x; ag2[i].y += d.y * xh[i].y; ag2[i].z += d.z * xh[i].z; ag2[i].w += d.w * xh[i].w;
+        ab2[i].x += d.x; ab2[i].y += d.y; ab2[i].z += d.z; ab2[i].w += d.w;
+        s1 += (dgv[i].x + dgv[i].y) + (dgv[i].z + dgv[i].w);
+        s2 += (dgv[i].x * xh[i].x + dgv[i].y * xh[i].y) + (dgv[i].z * xh[i].z + dgv[i].w * xh[i].w);
+      }
+    }
+    float a1 = wave_sum(s1) / (float)D, a2 = wave_sum(s2) / (float)D;
+    float4 d1[NV];   // gradient arriving at y1 (= output of LN1)
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        d1[i].x = r2 * (dgv[i].x - a1 - xh[i].x * a2);
+        d1[i].y = r2 * (dgv[i].y - a1 - xh[i].y * a2);
+        d1[i].z = r2 * (dgv[i].z - a1 - xh[i].z * a2);
+        d1[i].w = r2 * (dgv[i].w - a1 - xh[i].w * a2);
+        if (dres) {
+          const float4 e = *(const float4*)(dres + (long long)row * D + c * 4);
+          d1[i].x += e.x; d1[i].y += e.y; d1[i].z += e.z; d1[i].w += e.w;
+        }
+        // ---- LN1 backward: input x, upstream d1
+        const float4 zz = *(const float4*)(x + (long long)row * D + c * 4);
+        const float4 gm = *(const float4*)(g1 + c * 4);
+        xh[i] = make_float4((zz.x - m1) * r1, (zz.y - m1) * r1, (zz.z - m1) * r1, (zz.w - m1) * r1);
+        ag1[i].x += d1[i].x * xh[i].x; ag1[i].y += d1[i].y * xh[i].y; ag1[i].z += d1[i].z * xh[i].z; ag1[i].w += d1[i].w * xh[i].w;
+        ab1[i].x += d1[i].x; ab1[i].y += d1[i].y; ab1[i].z += d1[i].z; ab1[i].w += d1[i].w;
+        dgv[i] = make_float4(d1[i].x * gm.x, d1[i].y * gm.y, d1[i].z * gm.z, d1[i].w * gm.w);
+        s1 += (dgv[i].x + dgv[i].y) + (dgv[i].z + dgv[i].w);
+        s2 += (dgv[i].x * xh[i].x + dgv[i].y * xh[i].y) + (dgv[i].z * xh[i].z + dgv[i].w * xh[i].w);
+      }
+    }
+    a1 = wave_sum(s1) / (float)D; a2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float4 o;
+        o.x = r1 * (dgv[i].x - a1 - xh[i].x * a2);
+        o.y = r1 * (dgv[i].y - a1 - xh[i].y * a2);
+        o.z = r1 * (dgv[i].z - a1 - xh[i].z * a2);
+        o.w = r1 * (dgv[i].w - a1 - xh[i].w * a2);
+        *(float4*)(dx + (long long)row * D + c * 4) = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    red[w][0][lane + 64 * i] = ag1[i]; red[w][1][lane + 64 * i] = ab1[i];
+    red[w][2][lane + 64 * i] = ag2[i]; red[w][3][lane + 64 * i] = ab2[i];
+  }
+  __syncthreads();
+  float* outs[4] = {dg1, db1, dg2, db2};
+  float* out = outs[w];                 // wave w finishes parameter w
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float4 t = red[0][w][c];
+#pragma unroll
+      for (int ww = 1; ww < 4; ++ww) { const float4 u = red[ww][w][c]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      float4* dst = (float4*)(out + c * 4);
+      if (accumulate) { const float4 old = *dst; t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w; }
+      *dst = t;
+    }
+  }
+}
+
 // dgamma[d] (+)= sum_rows dy*xhat ; dbeta[d] (+)= sum_rows dy.  One workgroup per 64 columns.
 __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -736,6 +897,32 @@ extern "C" int ser_layernorm_bwd(const float* dy, const float* z, const float* m
   if (dgamma && dbeta)
     hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, st, dy, z, mean, rstd, rows, D, dgamma,
                        dbeta, accumulate_params);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_layernorm2_fwd(const float* x, const float* g1, const float* b1, const float* g2, const float* b2,
+                                  float eps, int rows, int D, float* y1, float* y2, float* stats, void* stream) {
+  SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm2_fwd: D=%d unsupported", D);
+  if (rows <= 0) return SER_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  LN_DISPATCH(ln2_fwd_kernel, ceil_div(D / 4, 64), x, g1, b1, g2, b2, eps, rows, D, y1, y2, stats);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_layernorm2_bwd(const float* du, const float* dres, const float* x, const float* y1, const float* stats,
+                                  const float* g1, const float* g2, int rows, int D, float* dx, float* dg1, float* db1,
+                                  float* dg2, float* db2, int accumulate, void* stream) {
+  SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 512, "layernorm2_bwd: D=%d unsupported (<= 512)", D);
+  if (rows <= 0) return SER_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(1), block(256);
+  if (D <= 256)
+    hipLaunchKernelGGL(ln2_bwd_kernel<1>, grid, block, 0, st, du, dres, x, y1, stats, g1, g2, rows, D, dx, dg1, db1, dg2, db2, accumulate);
+  else
+    hipLaunchKernelGGL(ln2_bwd_kernel<2>, grid, block, 0, st, du, dres, x, y1, stats, g1, g2, rows, D, dx, dg1, db1, dg2, db2, accumulate);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

@@ -74,13 +74,20 @@ class _ClassifierFn(torch.autograd.Function):
         h = O.act_fwd(y0, O.ACT_RELU)
         h0 = h
         blocks = []
+        fused_ln = h.shape[1] <= 512
         for blk, lno in zip(dc.residual_layers, dc.layer_norms):
             b = blk.block
-            x1, lnA = O.ln_fwd(h, lno.weight, lno.bias)
-            u, lnB = O.ln_fwd(x1, b[0].weight, b[0].bias)
+            hin = h
+            if fused_ln:
+                x1, u, stats = O.ln2_fwd(hin, lno.weight, lno.bias, b[0].weight, b[0].bias)
+                lnA = lnB = None
+            else:
+                x1, lnA = O.ln_fwd(hin, lno.weight, lno.bias)
+                u, lnB = O.ln_fwd(x1, b[0].weight, b[0].bias)
+                stats = None
             a = O.linear_fwd(u, b[1].weight, b[1].bias, O.ACT_RELU)
             h = O.linear_fwd(a, b[4].weight, b[4].bias, residual=x1)
-            blocks.append((lnA, lnB, u, a))
+            blocks.append((lnA, lnB, u, a, hin, x1, stats))
         tf = O.linear_fwd(h, op[0].weight, op[0].bias)
         yf, lnF = O.ln_fwd(tf, op[1].weight, op[1].bias)
         f = O.act_fwd(yf, O.ACT_RELU)
@@ -125,15 +132,17 @@ class _ClassifierFn(torch.autograd.Function):
         dh = O.linear_dgrad(dtf, op[0].weight)
         # residual stack, last block first
         for i in range(len(blocks) - 1, -1, -1):
-            lnA, lnB, u, a = blocks[i]
+            lnA, lnB, u, a, hin, x1, stats = blocks[i]
             b, lno = dc.residual_layers[i].block, dc.layer_norms[i]
-            O.linear_wgrad(dh, a, g(b[4].weight), g(b[4].bias), acc)
-            da = O.linear_dgrad(dh, b[4].weight)
-            O.act_bwd(da, a, O.ACT_RELU)
-            O.linear_wgrad(da, u, g(b[1].weight), g(b[1].bias), acc)
+            da = O.linear_dgrad(dh, b[4].weight, relu_mask=a)              # dgrad with ReLU' fused
+            O.linear_wgrad_pair(dh, a, g(b[4].weight), g(b[4].bias), da, u, g(b[1].weight), g(b[1].bias), acc)
             du = O.linear_dgrad(da, b[1].weight)
-            dx1 = O.ln_bwd(du, lnB, b[0].weight, g(b[0].weight), g(b[0].bias), acc, dx_add=dh)
-            dh = O.ln_bwd(dx1, lnA, lno.weight, g(lno.weight), g(lno.bias), acc)
+            if stats is not None:
+                dh = O.ln2_bwd(du, dh, hin, x1, stats, lno.weight, b[0].weight, g(lno.weight), g(lno.bias), g(b[0].weight),
+                               g(b[0].bias), acc)
+            else:
+                dx1 = O.ln_bwd(du, lnB, b[0].weight, g(b[0].weight), g(b[0].bias), acc, dx_add=dh)
+                dh = O.ln_bwd(dx1, lnA, lno.weight, g(lno.weight), g(lno.bias), acc)
         # input projection
         O.act_bwd(dh, h0, O.ACT_RELU)
         dt0 = O.ln_bwd(dh, ln0, ip[1].weight, g(ip[1].weight), g(ip[1].bias), acc)
