@@ -15,6 +15,16 @@ from .. import _ops as O
 from ._flat import FlatParams
 
 
+_SIDE = {}
+
+
+def _side_stream():
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream()
+    return _SIDE[dev]
+
+
 def _dir_fwd(x_q, x_kv, kv_mask, B, Sq, Sk, Wq, bq, Wk, bk, Wv, bv, Wi, bi, Wo, bo, Wout, bout, ng, nb, heads):
     E = Wq.shape[0]
     q1 = O.linear_fwd(x_q, Wq, bq)
@@ -64,12 +74,21 @@ class _CrossFn(torch.autograd.Function):
         a2, t2 = a.reshape(B * Sa, Da).contiguous(), t.reshape(B * St, Dt).contiguous()
         am = a_mask.to(torch.float32).contiguous() if a_mask is not None else None
         tm = t_mask.to(torch.float32).contiguous() if t_mask is not None else None
+        cur = torch.cuda.current_stream()
+        side = _side_stream()
+        side.wait_stream(cur)
         ya, sa = _dir_fwd(a2, t2, tm, B, Sa, St, m.q_a.weight, m.q_a.bias, m.k_t.weight, m.k_t.bias, m.v_t.weight,
                           m.v_t.bias, m.attn_a.in_proj_weight, m.attn_a.in_proj_bias, m.attn_a.out_proj.weight,
                           m.attn_a.out_proj.bias, m.out_a.weight, m.out_a.bias, m.norm_a.weight, m.norm_a.bias, m.num_heads)
-        yt, st = _dir_fwd(t2, a2, am, B, St, Sa, m.q_t.weight, m.q_t.bias, m.k_a.weight, m.k_a.bias, m.v_a.weight,
-                          m.v_a.bias, m.attn_t.in_proj_weight, m.attn_t.in_proj_bias, m.attn_t.out_proj.weight,
-                          m.attn_t.out_proj.bias, m.out_t.weight, m.out_t.bias, m.norm_t.weight, m.norm_t.bias, m.num_heads)
+        with torch.cuda.stream(side):     # T <- A is independent of A <- T
+            yt, st = _dir_fwd(t2, a2, am, B, St, Sa, m.q_t.weight, m.q_t.bias, m.k_a.weight, m.k_a.bias, m.v_a.weight,
+                              m.v_a.bias, m.attn_t.in_proj_weight, m.attn_t.in_proj_bias, m.attn_t.out_proj.weight,
+                              m.attn_t.out_proj.bias, m.out_t.weight, m.out_t.bias, m.norm_t.weight, m.norm_t.bias,
+                              m.num_heads)
+        cur.wait_stream(side)
+        for tns in (a2, t2):
+            tns.record_stream(side)
+        yt.record_stream(cur)
         ctx.m, ctx.dims = m, (B, Sa, St, Da, Dt)
         ctx.sa, ctx.st, ctx.a2, ctx.t2 = sa, st, a2, t2
         return ya.view(B, Sa, Da), yt.view(B, St, Dt)
@@ -83,12 +102,25 @@ class _CrossFn(torch.autograd.Function):
         g = fp.gview
         P = lambda mod: {"w": mod.weight, "b": mod.bias}
         PI = lambda mha: {"w": mha.in_proj_weight, "b": mha.in_proj_bias}
-        da = torch.zeros(B * Sa, Da, dtype=torch.float32, device=dya.device)
-        dt = torch.zeros(B * St, Dt, dtype=torch.float32, device=dya.device)
-        _dir_bwd(dya.reshape(B * Sa, Da).contiguous(), ctx.sa, ctx.a2, ctx.t2, B, Sa, St, P(m.q_a), P(m.k_t), P(m.v_t),
-                 PI(m.attn_a), P(m.attn_a.out_proj), P(m.out_a), P(m.norm_a), g, acc, m.num_heads, da, dt)
-        _dir_bwd(dyt.reshape(B * St, Dt).contiguous(), ctx.st, ctx.t2, ctx.a2, B, St, Sa, P(m.q_t), P(m.k_a), P(m.v_a),
-                 PI(m.attn_t), P(m.attn_t.out_proj), P(m.out_t), P(m.norm_t), g, acc, m.num_heads, dt, da)
+        dev = dya.device
+        da = torch.zeros(B * Sa, Da, dtype=torch.float32, device=dev)
+        dt = torch.zeros(B * St, Dt, dtype=torch.float32, device=dev)
+        da2 = torch.zeros(B * Sa, Da, dtype=torch.float32, device=dev)      # contributions of the other direction
+        dt2 = torch.zeros(B * St, Dt, dtype=torch.float32, device=dev)
+        dya2, dyt2 = dya.reshape(B * Sa, Da).contiguous(), dyt.reshape(B * St, Dt).contiguous()
+        cur = torch.cuda.current_stream()
+        side = _side_stream()
+        side.wait_stream(cur)
+        _dir_bwd(dya2, ctx.sa, ctx.a2, ctx.t2, B, Sa, St, P(m.q_a), P(m.k_t), P(m.v_t),
+                 PI(m.attn_a), P(m.attn_a.out_proj), P(m.out_a), P(m.norm_a), g, acc, m.num_heads, da, dt2)
+        with torch.cuda.stream(side):     # the two directions touch disjoint parameters and disjoint gradient buffers
+            _dir_bwd(dyt2, ctx.st, ctx.t2, ctx.a2, B, St, Sa, P(m.q_t), P(m.k_a), P(m.v_a),
+                     PI(m.attn_t), P(m.attn_t.out_proj), P(m.out_t), P(m.norm_t), g, acc, m.num_heads, dt, da2)
+        cur.wait_stream(side)
+        for tns in (dyt2, dt, da2):
+            tns.record_stream(side)
+        O.axpby(da2, da, 1.0, 1.0)
+        O.axpby(dt2, dt, 1.0, 1.0)
         fp.publish()
         ctx.sa = ctx.st = None
         return (None, da.view(B, Sa, Da), dt.view(B, St, Dt), None, None) + (None,) * len(fp.params)

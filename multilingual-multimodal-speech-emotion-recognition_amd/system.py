@@ -36,6 +36,7 @@ class SERSystem(nn.Module):
         self.criterion = TrainLoss(num_labels)
         self.num_labels = num_labels
         self._graph = None
+        self._side = None
 
     # ---- reference checkpoint layout (train.py:249-262) ---------------------------------------------------------
     CKPT_KEYS = ("audio_encoder", "text_encoder", "cross", "pool_a", "pool_t", "fusion", "classifier", "prototypes")
@@ -65,15 +66,38 @@ class SERSystem(nn.Module):
 
     # ---- forward pieces ------------------------------------------------------------------------------------------
     def encode(self, wave, ids, attn_mask):
+        """The two encoders are independent until cross-attention: the (small, 96-288-workgroup) XLM-R kernels run on
+        a second stream underneath the Wav2Vec2 ones instead of after them.  Under graph capture this becomes
+        two parallel branches of the graph."""
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            t_seq, t_mask = self.text_encoder.forward_ids(ids, attn_mask)
         a_seq = self.audio_encoder.encode(wave)
         a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
-        t_seq, t_mask = self.text_encoder.forward_ids(ids, attn_mask)
+        cur.wait_stream(side)
+        t_seq.record_stream(cur)
+        t_mask.record_stream(cur)
         return a_seq, a_mask, t_seq, t_mask
 
     def head(self, a_seq, a_mask, t_seq, t_mask):
         a_enh, t_enh = self.cross(a_seq, t_seq, a_mask, t_mask)
+        # the two poolings are independent: text pooling (forward, and therefore its backward, which autograd runs
+        # on the forward's stream) goes to the side stream
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            t_vec = self.pool_t(t_enh, t_mask)
+        t_enh.record_stream(side)
         a_vec = self.pool_a(a_enh, a_mask)
-        t_vec = self.pool_t(t_enh, t_mask)
+        cur.wait_stream(side)
+        t_vec.record_stream(cur)
         return self.fusion(a_vec, t_vec)
 
     def forward(self, wave, ids, attn_mask, use_openmax=True):
