@@ -350,6 +350,57 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_dgrad_kernel(const float* _
   }
 }
 
+
+// 16-column variant of the skinny dgrad: four times as many workgroups pull the weight matrix (the M = batch
+// classifier is bound by how many CUs stream weights, not by FLOPs); one 4-byte load per lane per weight row.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_dgrad16_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                                    const float* __restrict__ relu_mask,
+                                                                    float* __restrict__ dx, int M, int N, int Kc,
+                                                                    int accumulate) {
+  __shared__ float red[WAVES][64][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int c = blockIdx.x * 16 + i;
+  const bool cok = c < Kc;
+  const int cc = cok ? c : 0;
+  const float* dyr = dy + (long long)min(i, M - 1) * N;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (N + 3) >> 2;
+  const int nit = (nsteps - w + WAVES - 1) / WAVES;
+  for (int it = 0; it < nit; it += 16) {
+    float a[16], b[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int n = min((w + (it + u) * WAVES) * 4 + q, N - 1);
+      a[u] = dyr[n];
+      b[u] = W[(long long)n * Kc + cc];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int n = (w + (it + u) * WAVES) * 4 + q;
+      const float av = (it + u < nit && n < N) ? a[u] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u], acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+  __syncthreads();
+  if (w == 0 && cok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = q * 4 + r;
+      if (m >= M) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < WAVES; ++ww) v += red[ww][lane][r];
+      if (relu_mask) v = relu_mask[(long long)m * Kc + c] > 0.f ? v : 0.f;
+      float* dst = dx + (long long)m * Kc + c;
+      *dst = accumulate ? *dst + v : v;
+    }
+  }
+}
+
 // dW[N,Kc] (+)= dy[M<=16,N]^T . x[M,Kc] ; db[N] (+)= sum_m dy[m,n]
 struct SkinnyWgradArgs {
   const float *dy, *x;
@@ -512,13 +563,17 @@ extern "C" int ser_linear_fwd(const float* x, const float* W, const float* bias,
 
 // dx[M,K] (+)= dy[M,N] W[N,K]
 extern "C" int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);
+static int g_dgrad16 = 1;
+extern "C" int ser_debug_set_dgrad16(int v) { g_dgrad16 = v; return 0; }
 
 extern "C" int ser_linear_dgrad(const float* dy, const float* W, const float* relu_mask, float* dx, int M, int N, int K,
                                 int accumulate, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (M <= 16 && K % 4 == 0 && aligned16(W) && aligned16(dx)) {
     SER_REQUIRE(M > 0 && N > 0 && K > 0, "linear_dgrad: empty problem");
-    if (N >= 128)
+    if (N >= 128 && g_dgrad16)
+      hipLaunchKernelGGL(skinny_dgrad16_kernel<8>, dim3(ceil_div(K, 16)), dim3(512), 0, st, dy, W, relu_mask, dx, M, N, K, accumulate);
+    else if (N >= 128)
       hipLaunchKernelGGL(skinny_dgrad_kernel<8>, dim3(ceil_div(K, 64)), dim3(512), 0, st, dy, W, relu_mask, dx, M, N, K, accumulate);
     else
       hipLaunchKernelGGL(skinny_dgrad_kernel<2>, dim3(ceil_div(K, 64)), dim3(128), 0, st, dy, W, relu_mask, dx, M, N, K, accumulate);

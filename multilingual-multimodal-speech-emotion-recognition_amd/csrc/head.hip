@@ -176,21 +176,22 @@ __global__ __launch_bounds__(256) void ln2_fwd_kernel(const float* __restrict__ 
 // du = grad wrt y2, dres = extra grad arriving at y1 (the residual branch).  dx = LN1'(LN2'(du) + dres).
 // One workgroup walks all rows (rows = batch, small): wave w takes rows w, w+4, ...; the parameter gradients
 // are accumulated per lane over the wave's rows and reduced across the four waves through LDS.
+constexpr int LN2_WAVES = 8;
 template <int NV>
-__global__ __launch_bounds__(256) void ln2_bwd_kernel(const float* __restrict__ du, const float* __restrict__ dres,
+__global__ __launch_bounds__(LN2_WAVES * 64) void ln2_bwd_kernel(const float* __restrict__ du, const float* __restrict__ dres,
                                                       const float* __restrict__ x, const float* __restrict__ y1,
                                                       const float* __restrict__ stats, const float* __restrict__ g1,
                                                       const float* __restrict__ g2, int rows, int D,
                                                       float* __restrict__ dx, float* __restrict__ dg1,
                                                       float* __restrict__ db1, float* __restrict__ dg2,
                                                       float* __restrict__ db2, int accumulate) {
-  __shared__ float4 red[4][4][NV * 64];    // [wave][which param][chunk]
+  __shared__ float4 red[LN2_WAVES][4][NV * 64];    // [wave][which param][chunk]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   float4 ag1[NV], ab1[NV], ag2[NV], ab2[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ag1[i] = ab1[i] = ag2[i] = ab2[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int row = w; row < rows; row += 4) {
+  for (int row = w; row < rows; row += LN2_WAVES) {
     const float m1 = stats[row], r1 = stats[rows + row], m2 = stats[2 * rows + row], r2 = stats[3 * rows + row];
     float4 xh[NV], dgv[NV];
     float s1 = 0.f, s2 = 0.f;
@@ -256,15 +257,15 @@ __global__ __launch_bounds__(256) void ln2_bwd_kernel(const float* __restrict__ 
     red[w][2][lane + 64 * i] = ag2[i]; red[w][3][lane + 64 * i] = ab2[i];
   }
   __syncthreads();
-  float* outs[4] = {dg1, db1, dg2, db2};
-  float* out = outs[w];                 // wave w finishes parameter w
+  if (w >= 4) return;
+  float* out = w == 0 ? dg1 : (w == 1 ? db1 : (w == 2 ? dg2 : db2));   // wave w finishes parameter w
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
       float4 t = red[0][w][c];
 #pragma unroll
-      for (int ww = 1; ww < 4; ++ww) { const float4 u = red[ww][w][c]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+      for (int ww = 1; ww < LN2_WAVES; ++ww) { const float4 u = red[ww][w][c]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
       float4* dst = (float4*)(out + c * 4);
       if (accumulate) { const float4 old = *dst; t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w; }
       *dst = t;
@@ -918,7 +919,7 @@ extern "C" int ser_layernorm2_bwd(const float* du, const float* dres, const floa
   SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 512, "layernorm2_bwd: D=%d unsupported (<= 512)", D);
   if (rows <= 0) return SER_OK;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(1), block(256);
+  dim3 grid(1), block(LN2_WAVES * 64);
   if (D <= 256)
     hipLaunchKernelGGL(ln2_bwd_kernel<1>, grid, block, 0, st, du, dres, x, y1, stats, g1, g2, rows, D, dx, dg1, db1, dg2, db2, accumulate);
   else
