@@ -159,8 +159,16 @@ def main():
         ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
         L.check(L.lib.ser_prof_gemm_stop(C.byref(ms), C.byref(fl), C.byref(n)))
         achieved = fl.value / (ms.value * 1e-3) / 1e12
+        # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE, separate --pmc runs; see profiles/): bench.py cannot run the profiler itself
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
+                traffic = round(json.load(fh)["gemm_bf16"]["hbm_bytes_per_launch"])
+        except Exception:  # noqa: BLE001
+            traffic = None
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                     kernel="gemm_bf16_nt_kernel", launches_per_step=n.value // nprof,
                     avg_launch_us=round(ms.value * 1e3 / max(1, n.value), 2),
                     algorithmic_gflop_per_step=round(fl.value / nprof / 1e9, 1),
