@@ -108,13 +108,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SER_SINGLE_DEVICE"):      # rehearsal: every rank shares GPU 0 (gloo backend)
+        local = 0
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU fallback of the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SER_DIST_BACKEND", "nccl")      # "nccl" == RCCL on ROCm; gloo only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ser_amd.system import GradReducer, TrainStepper
     from ser_amd import _lib as L
@@ -123,7 +129,8 @@ def main():
     opt = sysm.make_optimizer(lr=1e-4)
     reducer = GradReducer(sysm) if world > 1 else None
     use_graph = not args.no_graph
-    stepper = TrainStepper(sysm, opt, None, reducer, use_graph=use_graph)
+    split = None if "SER_SPLIT_BACKWARD" not in os.environ else os.environ["SER_SPLIT_BACKWARD"] == "1"
+    stepper = TrainStepper(sysm, opt, None, reducer, use_graph=use_graph, split_backward=split)
     batch = [t.to(dev) for t in synth_batch(args.batch, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels, 1234 + rank)]
 
     for _ in range(max(1, args.warmup)):

@@ -90,19 +90,24 @@ def test_graph_step_equals_eager_step():
     sys_a, wc, xc = ge._small_system(dev)
     sys_b, _, _ = ge._small_system(dev)
     sys_b.load_state_dict(sys_a.state_dict())
+    sys_c, _, _ = ge._small_system(dev)
+    sys_c.load_state_dict(sys_a.state_dict())
     steppers = []
-    for s, graph in ((sys_a, False), (sys_b, True)):
+    for s, graph, split in ((sys_a, False, False), (sys_b, True, False), (sys_c, True, True)):
         s.train()
         opt = s.make_optimizer(lr=1e-3)
-        steppers.append(TrainStepper(s, opt, WarmupCosine(opt, 10, 0.0), use_graph=graph))
+        steppers.append(TrainStepper(s, opt, WarmupCosine(opt, 10, 0.0), use_graph=graph, split_backward=split))
     for it in range(3):
         batch = [t.to(dev) for t in _batch(100 + it)]
         la = steppers[0].step(*batch)
         lb = steppers[1].step(*batch)
+        lc = steppers[2].step(*batch)        # the two-piece backward used under data parallelism
         torch.cuda.synchronize()
         assert abs(la.item() - lb.item()) < 1e-6, f"step {it}: eager {la.item()} vs graph {lb.item()}"
-    for (n, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
+        assert abs(la.item() - lc.item()) < 1e-6, f"step {it}: eager {la.item()} vs split graph {lc.item()}"
+    for (n, pa), (_, pb), (_, pc) in zip(sys_a.named_parameters(), sys_b.named_parameters(), sys_c.named_parameters()):
         assert torch.equal(pa, pb), f"{n}: parameters diverged between eager and graph stepping"
+        assert torch.equal(pa, pc), f"{n}: parameters diverged between eager and split-graph stepping"
 
 
 def test_variable_length_clips_pad_like_reference():
