@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16",
                     help="bf16: one bf16 MFMA per product (BASELINE config). bf16x3: split-operand parity mode")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run encoders and head back to back instead of encoder(t+1) beside head(t)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -131,17 +133,27 @@ def main():
     use_graph = not args.no_graph
     split = None if "SER_SPLIT_BACKWARD" not in os.environ else os.environ["SER_SPLIT_BACKWARD"] == "1"
     stepper = TrainStepper(sysm, opt, None, reducer, use_graph=use_graph, split_backward=split)
-    batch = [t.to(dev) for t in synth_batch(args.batch, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels, 1234 + rank)]
-
+    # four distinct device-resident batches, visited round-robin: nothing can be reused from one step to the next
+    batches = [[t.to(dev) for t in synth_batch(args.batch, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels,
+                                               1234 + rank + 1000 * j)] for j in range(4)]
+    batch = batches[0]
+    pipeline = use_graph and not args.no_pipeline
+    if pipeline:
+        from ser_amd.system import PipelinedStepper
+        stepper = PipelinedStepper(sysm, opt, None, reducer)
+        stepper.feed(*batches[0])       # encoders of the first batch; every step() then does one encoder pass + one update
+    it = 0
     for _ in range(max(1, args.warmup)):
-        stepper.step(*batch)
+        it += 1
+        stepper.step(*batches[it % 4])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        stepper.step(*batch)
+        it += 1
+        stepper.step(*batches[it % 4])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,10 +206,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "RAVDESS-shaped synthetic: %gs@16kHz waveform + %d-token text, batch %d per GPU, "
-                                   "Wav2Vec2-Base + XLM-R-Base frozen (random init), adapters + cross-attention + pooling + "
-                                   "gated fusion + 35-block OpenMax classifier trained, AdamW" % (args.seconds, args.tokens, args.batch),
+                                   "%s frozen (random init), adapters + cross-attention + pooling + "
+                                   "gated fusion + 35-block OpenMax classifier trained, AdamW"
+                                   % (args.seconds, args.tokens, args.batch,
+                                      "Large-sized (1024-d, 24-layer) Wav2Vec2 + XLM-R" if args.stress else "Wav2Vec2-Base + XLM-R-Base"),
                        "global_batch": world * args.batch, "precision": args.precision,
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
+                       "schedule": "frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "
+                                   "(two streams; one encoder pass and one update per step)" if pipeline else "sequential",
                        "stress_sizes": bool(args.stress)},
             "roofline": roof, "cpu_baseline": cpu,
             "logit_max_abs_err_vs_cpu_oracle": err, "class_indices_equal": same,

@@ -110,6 +110,30 @@ def test_graph_step_equals_eager_step():
         assert torch.equal(pa, pc), f"{n}: parameters diverged between eager and split-graph stepping"
 
 
+def test_pipelined_stepping_is_bit_identical_to_sequential():
+    import __graft_entry__ as ge
+    from ser_amd.system import PipelinedStepper, TrainStepper
+    dev = torch.device("cuda:0")
+    sys_a, _, _ = ge._small_system(dev)
+    sys_b, _, _ = ge._small_system(dev)
+    sys_b.load_state_dict(sys_a.state_dict())
+    sys_a.train(); sys_b.train()
+    oa, ob = sys_a.make_optimizer(lr=1e-3), sys_b.make_optimizer(lr=1e-3)
+    seq = TrainStepper(sys_a, oa, use_graph=False)
+    pipe = PipelinedStepper(sys_b, ob)
+    batches = [[t.to(dev) for t in _batch(200 + i)] for i in range(5)]
+    seq_losses = [seq.step(*b).item() for b in batches]
+    pipe.feed(*batches[0])
+    pipe_losses = []
+    for i in range(5):
+        nxt = batches[i + 1] if i + 1 < 5 else batches[0]
+        pipe_losses.append(pipe.step(*nxt).item())
+    torch.cuda.synchronize()
+    assert seq_losses == pipe_losses, (seq_losses, pipe_losses)
+    for (n, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
+        assert torch.equal(pa, pb), f"{n}: pipelined stepping diverged from sequential stepping"
+
+
 def test_variable_length_clips_pad_like_reference():
     import __graft_entry__ as ge
     dev = torch.device("cuda:0")
