@@ -17,6 +17,7 @@ from .models.cross_attention import CrossModalAttention
 from .models.pooling import AttentiveStatsPooling
 from .models.losses import TrainLoss
 from .models.prototypes import PrototypeMemory
+from . import _ops
 from .optim import FlatAdamW, WarmupCosine
 
 
@@ -262,6 +263,7 @@ class TrainStepper:
     def _fwd_bwd(self, wave, ids, mask, labels):
         loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto)
         loss.backward()
+        _ops.wgrad_join()
         return loss.detach(), logits.detach()
 
     # ---- split form: the classifier + loss hang off a detached copy of `fused`
@@ -272,11 +274,13 @@ class TrainStepper:
         logits, unc, _ = s.classifier(leaf, use_openmax=False, return_uncertainty=True)
         loss = s.criterion(logits, unc, leaf, s.prototypes.prototypes, labels, use_proto=self.use_proto)
         loss.backward()
+        _ops.wgrad_join()
         self._fused, self._dfused = fused, leaf.grad
         return loss.detach(), logits.detach()
 
     def _bwd_b(self):
         self._fused.backward(self._dfused)
+        _ops.wgrad_join()
         self._fused = self._dfused = None
 
     def step(self, wave, ids, mask, labels):
@@ -402,6 +406,7 @@ class PipelinedStepper:
         with torch.cuda.graph(self.g_head):
             loss, logits = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
             loss.backward()
+            _ops.wgrad_join()
             self.loss, self.logits = loss.detach(), logits.detach()
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt):
