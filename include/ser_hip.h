@@ -45,6 +45,10 @@ extern "C" {
 const char* ser_last_error_string(void);
 int ser_abi_version(void);
 
+/* HIP stream restricted to the compute units whose bits are set in mask[words] (hipExtStreamCreateWithCUMask). */
+int ser_stream_create_cu_masked(const uint32_t* mask, int words, void** stream_out);
+int ser_stream_destroy(void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * op-level entry points (used by the parity tests and composed by the module-level calls)
  * ------------------------------------------------------------------------------------------- */

@@ -70,6 +70,8 @@ def _sig(name, restype, *argtypes):
 
 _sig("ser_last_error_string", C.c_char_p)
 _sig("ser_abi_version", i32)
+_sig("ser_stream_create_cu_masked", i32, C.POINTER(C.c_uint32), i32, C.POINTER(vp))
+_sig("ser_stream_destroy", i32, vp)
 _sig("ser_prof_gemm_start", i32)
 _sig("ser_prof_gemm_stop", i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong))
 _sig("ser_split_bf16", i32, vp, vp, vp, i64, vp)
@@ -95,6 +97,17 @@ def ptr(t):
         return None
     assert t.is_cuda and t.is_contiguous(), "libser_hip needs contiguous device tensors"
     return t.data_ptr()
+
+
+def cu_masked_stream(bits):
+    """torch ExternalStream on a HIP stream limited to the CUs listed in `bits` (iterable of CU indices)."""
+    words = [0] * 8
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    arr = (C.c_uint32 * 8)(*words)
+    out = vp()
+    check(lib.ser_stream_create_cu_masked(arr, 8, C.byref(out)), "ser_stream_create_cu_masked")
+    return torch.cuda.ExternalStream(out.value)
 
 
 def stream_ptr():

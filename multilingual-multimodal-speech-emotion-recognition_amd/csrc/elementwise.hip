@@ -13,6 +13,21 @@ void ser_set_error(const char* fmt, ...) {
 extern "C" const char* ser_last_error_string(void) { return g_err; }
 extern "C" int ser_abi_version(void) { return 1; }
 
+// A HIP stream restricted to a subset of the compute units (bit i of mask word i/32 = CU i in the runtime's
+// enumeration).  Used to keep a few CUs free for the latency-bound head kernels while the encoder GEMMs of the next
+// batch run on the rest.  The caller owns the stream (ser_stream_destroy).
+extern "C" int ser_stream_create_cu_masked(const uint32_t* mask, int words, void** stream_out) {
+  SER_REQUIRE(mask && words > 0 && stream_out, "stream_create_cu_masked: bad arguments");
+  hipStream_t st = nullptr;
+  SER_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+  *stream_out = (void*)st;
+  return SER_OK;
+}
+extern "C" int ser_stream_destroy(void* stream) {
+  if (stream) SER_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return SER_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // fp32 -> split bf16 planes
 // ------------------------------------------------------------------------------------------

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Stand-alone durations of the captured graphs of the pipelined step (encoders | head fwd+bwd | AdamW)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from ser_amd.system import PipelinedStepper
+
+dev = torch.device("cuda:0")
+sysm, wc, xc = bench.build_system("bf16", dev)
+sysm.train()
+opt = sysm.make_optimizer(1e-4)
+st = PipelinedStepper(sysm, opt)
+b = [t.to(dev) for t in bench.synth_batch(16, 4.0, 32, xc.vocab_size, 4, 1)]
+st.feed(*b)
+for _ in range(3):
+    st.step(*b)
+torch.cuda.synchronize()
+
+
+def t(fn, n=20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+print("encoder graph alone  %.3f ms" % t(st.g_enc.replay))
+print("head graph alone     %.3f ms" % t(st.g_head.replay))
+print("adamw graph alone    %.3f ms" % t(st.g_opt.replay))
+print("pipelined step       %.3f ms" % t(lambda: st.step(*b)))
