@@ -190,9 +190,10 @@ int ser_linear_wgrad(const float* dy, const float* x, float* dW, float* db, int 
  * classifier.py:79,107,118,125); backward gives dx (+ dx_add) and dgamma/dbeta. */
 int ser_layernorm_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float eps,
                       int rows, int D, float* y, float* z, float* mean, float* rstd, void* stream);
+size_t ser_layernorm_bwd_workspace_bytes(int rows, int D); /* 0 for few rows; else partial dgamma/dbeta slices */
 int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
                       const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
-                      float* dbeta, int accumulate_params, void* stream);
+                      float* dbeta, int accumulate_params, void* workspace, void* stream);
 
 /* the two chained LayerNorms of a classifier block (classifier.py:209-210) fused: forward keeps
  * stats[4][rows] = mean1, rstd1, mean2, rstd2; backward returns dx = LN1'(LN2'(du) + dres) and all four

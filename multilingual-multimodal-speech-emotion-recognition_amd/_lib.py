@@ -166,7 +166,8 @@ _sig("ser_layernorm2_bwd", i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp
 _sig("ser_linear_wgrad_workspace_bytes", sz, i32, i32, i32)
 _sig("ser_linear_wgrad", i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp)
 _sig("ser_layernorm_fwd", i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp, vp)
-_sig("ser_layernorm_bwd", i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp)
+_sig("ser_layernorm_bwd_workspace_bytes", sz, i32, i32)
+_sig("ser_layernorm_bwd", i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp)
 _sig("ser_colsum", i32, vp, i32, i32, i32, vp, i32, vp)
 _sig("ser_act_fwd", i32, vp, i32, i64, vp, vp)
 _sig("ser_act_bwd", i32, vp, vp, i32, i64, vp, vp)

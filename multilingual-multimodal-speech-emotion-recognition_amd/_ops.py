@@ -152,9 +152,11 @@ def ln_bwd(dy, saved, gamma, dgamma=None, dbeta=None, accumulate=False, dx_add=N
     z, mean, rstd = saved
     rows, D = dy.shape
     dx = torch.empty_like(dy) if need_dx else None
+    nb = L.lib.ser_layernorm_bwd_workspace_bytes(rows, D)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dy.device) if nb else None
     L.check(L.lib.ser_layernorm_bwd(L.ptr(dy), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dx_add), rows, D,
-                                    L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, L.stream_ptr()),
-            "ser_layernorm_bwd")
+                                    L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), 1 if accumulate else 0, L.ptr(ws),
+                                    L.stream_ptr()), "ser_layernorm_bwd")
     return dx
 
 

@@ -273,17 +273,23 @@ __global__ __launch_bounds__(LN2_WAVES * 64) void ln2_bwd_kernel(const float* __
   }
 }
 
-// dgamma[d] (+)= sum_rows dy*xhat ; dbeta[d] (+)= sum_rows dy.  One workgroup per 64 columns.
+// dgamma[d] (+)= sum_rows dy*xhat ; dbeta[d] (+)= sum_rows dy.
+// grid = (D/64 column tiles, row slices).  With one slice the result is written directly; with several, each
+// workgroup writes a partial to `part[slice][2][D]` and ln_bwd_param_reduce_kernel adds them in slice order
+// (deterministic; many-token LayerNorms would otherwise run on D/64 workgroups only).
 __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            int rows, int D, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
+                                                           float* __restrict__ dbeta, int accumulate,
+                                                           float* __restrict__ part) {
   __shared__ float sg[4][64], sb[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rg = threadIdx.x >> 6;
+  const int nsl = gridDim.y, per = (rows + nsl - 1) / nsl;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   float ag = 0.f, ab = 0.f;
   if (col < D)
-    for (int r = rg; r < rows; r += 4) {
+    for (int r = r0 + rg; r < r1; r += 4) {
       const float d = dy[(long long)r * D + col];
       ag = fmaf(d, (z[(long long)r * D + col] - mean[r]) * rstd[r], ag);
       ab += d;
@@ -295,9 +301,27 @@ __global__ __launch_bounds__(256) void ln_bwd_param_kernel(const float* __restri
     const int c = threadIdx.x;
     const float g = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
     const float b = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
-    dgamma[col] = accumulate ? dgamma[col] + g : g;
-    dbeta[col] = accumulate ? dbeta[col] + b : b;
+    if (part) {
+      part[((long long)blockIdx.y * 2) * D + col] = g;
+      part[((long long)blockIdx.y * 2 + 1) * D + col] = b;
+    } else {
+      dgamma[col] = accumulate ? dgamma[col] + g : g;
+      dbeta[col] = accumulate ? dbeta[col] + b : b;
+    }
   }
+}
+
+__global__ void ln_bwd_param_reduce_kernel(const float* __restrict__ part, int nsl, int D, float* __restrict__ dgamma,
+                                           float* __restrict__ dbeta, int accumulate) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= D) return;
+  float g = 0.f, b = 0.f;
+  for (int s = 0; s < nsl; ++s) {
+    g += part[((long long)s * 2) * D + col];
+    b += part[((long long)s * 2 + 1) * D + col];
+  }
+  dgamma[col] = accumulate ? dgamma[col] + g : g;
+  dbeta[col] = accumulate ? dbeta[col] + b : b;
 }
 
 // out[n] (+)= sum_m x[m*ld + n]
@@ -885,9 +909,14 @@ extern "C" int ser_layernorm_fwd(const float* x, const float* x2, const float* g
   return SER_OK;
 }
 
+extern "C" size_t ser_layernorm_bwd_workspace_bytes(int rows, int D) {
+  const int nsl = rows >= 512 ? 32 : 1;
+  return nsl > 1 ? (size_t)nsl * 2 * D * sizeof(float) : 0;
+}
+
 extern "C" int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
                                  const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
-                                 float* dbeta, int accumulate_params, void* stream) {
+                                 float* dbeta, int accumulate_params, void* workspace, void* stream) {
   SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D=%d unsupported", D);
   if (rows <= 0) return SER_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -895,9 +924,15 @@ extern "C" int ser_layernorm_bwd(const float* dy, const float* z, const float* m
     dim3 grid(ceil_div(rows, 4)), block(256);
     LN_DISPATCH(ln_bwd_dx_kernel, ceil_div(D / 4, 64), dy, z, mean, rstd, gamma, dx_add, rows, D, dx);
   }
-  if (dgamma && dbeta)
-    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, st, dy, z, mean, rstd, rows, D, dgamma,
-                       dbeta, accumulate_params);
+  if (dgamma && dbeta) {
+    const int nsl = (rows >= 512 && workspace) ? 32 : 1;
+    float* part = nsl > 1 ? (float*)workspace : nullptr;
+    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(ceil_div(D, 64), nsl), dim3(256), 0, st, dy, z, mean, rstd, rows, D, dgamma,
+                       dbeta, accumulate_params, part);
+    if (part)
+      hipLaunchKernelGGL(ln_bwd_param_reduce_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, part, nsl, D, dgamma, dbeta,
+                         accumulate_params);
+  }
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
