@@ -474,6 +474,142 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// fp32-in / fp32-out GEMM on the bf16 matrix cores with split operands (three products per MAC, ~2^-16 relative
+// error per product): the token-level products of the head (adapters, cross-attention projections, pooling
+// scorer; M = B*S rows) are bound by the fp32 MFMA rate (1/16 of bf16) in gemm_f32_kernel, so here each staged
+// fp32 tile is split into hi/lo bf16 planes on its way into LDS (v_cvt_pk_bf16_f32) and multiplied with
+// v_mfma_f32_16x16x32_bf16.  Same argument record, layouts (AKF/BKF), split-K and fused bias-gradient row sums as
+// gemm_f32_kernel.  64x64 tile, BK = 32; LDS planes are [row][32 bf16] with the 16-byte chunk index XORed by
+// 2*bit3(row) (conflict-free ds_read_b128 fragments).
+// ------------------------------------------------------------------------------------------
+constexpr int X3_BK = 32;
+SER_DEVFN int x3_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4); }
+
+template <int AKF, int BKF>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
+  constexpr int PLANE = 64 * 64;                     // bytes: 64 rows x 32 bf16
+  __shared__ __attribute__((aligned(16))) char lds[2][4 * PLANE];   // [stage][A_hi, A_lo, B_hi, B_lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int kbeg = g.k_chunk ? blockIdx.z * g.k_chunk : 0;
+  const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
+  const int nk = (kend - kbeg) / X3_BK;
+  const bool want_rowsum = g.ws_rowsum != nullptr && blockIdx.x == 0 && tid < 64;
+  float rowsum = 0.f;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[2], rb[2];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int gi = tid + 256 * e;
+      if (AKF) { const int r = min(m0 + gi / 8, g.M - 1), k = (gi % 8) * 4; ra[e] = *(const float4*)(g.a + (long long)r * g.sam + k0 + k); }
+      else { const int k = gi / 16, r = min(m0 + (gi % 16) * 4, g.M - 4); ra[e] = *(const float4*)(g.a + (long long)(k0 + k) * g.sak + r); }
+      if (BKF) { const int r = min(n0 + gi / 8, g.N - 1), k = (gi % 8) * 4; rb[e] = *(const float4*)(g.b + (long long)r * g.sbn + k0 + k); }
+      else { const int k = gi / 16, r = min(n0 + (gi % 16) * 4, g.N - 4); rb[e] = *(const float4*)(g.b + (long long)(k0 + k) * g.sbk + r); }
+    }
+  };
+  auto store_one = [&](char* hi, char* lo, const float4 v, int gi, bool kf) {
+    uint32_t h0, l0, h1, l1;
+    split_bf16x2(v.x, v.y, h0, l0);
+    split_bf16x2(v.z, v.w, h1, l1);
+    if (kf) {
+      const int r = gi / 8, k = (gi % 8) * 4;
+      const int off = x3_off(r, k >> 3) + (k & 7) * 2;
+      *(uint2*)(hi + off) = make_uint2(h0, h1);
+      *(uint2*)(lo + off) = make_uint2(l0, l1);
+    } else {
+      const int k = gi / 16, r = (gi % 16) * 4;
+      const int kb = (k & 7) * 2, ch = k >> 3;
+      *(uint16_t*)(hi + x3_off(r, ch) + kb) = (uint16_t)h0;
+      *(uint16_t*)(hi + x3_off(r + 1, ch) + kb) = (uint16_t)(h0 >> 16);
+      *(uint16_t*)(hi + x3_off(r + 2, ch) + kb) = (uint16_t)h1;
+      *(uint16_t*)(hi + x3_off(r + 3, ch) + kb) = (uint16_t)(h1 >> 16);
+      *(uint16_t*)(lo + x3_off(r, ch) + kb) = (uint16_t)l0;
+      *(uint16_t*)(lo + x3_off(r + 1, ch) + kb) = (uint16_t)(l0 >> 16);
+      *(uint16_t*)(lo + x3_off(r + 2, ch) + kb) = (uint16_t)l1;
+      *(uint16_t*)(lo + x3_off(r + 3, ch) + kb) = (uint16_t)(l1 >> 16);
+    }
+  };
+  auto store = [&](int buf) {
+    char* s = lds[buf];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      store_one(s, s + PLANE, ra[e], tid + 256 * e, AKF != 0);
+      store_one(s + 2 * PLANE, s + 3 * PLANE, rb[e], tid + 256 * e, BKF != 0);
+    }
+  };
+
+  load(kbeg);
+  store(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load(kbeg + (kt + 1) * X3_BK);
+    const char* s = lds[cur];
+    if (want_rowsum) {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        const bf16x8 h = *(const bf16x8*)(s + x3_off(tid, ch)), l = *(const bf16x8*)(s + PLANE + x3_off(tid, ch));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rowsum += bf2f((bf16_t)h[e]) + bf2f((bf16_t)l[e]);
+      }
+    }
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = x3_off(wm * 32 + i * 16 + fr, fq);
+      ah[i] = *(const bf16x8*)(s + off);
+      al[i] = *(const bf16x8*)(s + PLANE + off);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int off = x3_off(wn * 32 + j * 16 + fr, fq);
+      bh[j] = *(const bf16x8*)(s + 2 * PLANE + off);
+      bl[j] = *(const bf16x8*)(s + 3 * PLANE + off);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (kt + 1 < nk) store(cur ^ 1);
+    __syncthreads();
+  }
+
+  if (want_rowsum && m0 + tid < g.M) g.ws_rowsum[(long long)blockIdx.z * g.M + m0 + tid] = rowsum;
+  float* wsz = g.ws ? g.ws + (long long)blockIdx.z * g.M * g.N : nullptr;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wn * 32 + j * 16 + fr;
+    if (n >= g.N) continue;
+    const float bv = (g.bias && !wsz) ? g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + fq * 4 + r;
+        if (m >= g.M) continue;
+        if (wsz) { wsz[(long long)m * g.N + n] = acc[i][j][r]; continue; }
+        float v = act_f32(acc[i][j][r] + bv, g.act);
+        if (g.residual) v += g.residual[(long long)m * g.ldr + n];
+        float* cp = g.c + (long long)m * g.ldc + n;
+        *cp = g.accumulate ? *cp + v : v;
+      }
+  }
+}
+
 }  // namespace
 
 static int g_f32_bk = 0;   // 0 = automatic
@@ -491,7 +627,23 @@ static void launch_6464_bk(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_f32_kernel<64, 64, FBK, 2, 2, 2>), grid, block, 0, st, g);
 }
 static int g_f32_bk_fwd();
+static int g_use_x3 = 1;   // token-level head products on split-bf16 MFMA (0: exact fp32 MFMA)
+extern "C" int ser_debug_set_head_x3(int v) { g_use_x3 = v; return 0; }
+
 static void launch_6464(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
+  {
+    const int kext = g.k_chunk ? g.k_chunk : g.K;
+    const bool ok = g_use_x3 && g.vec_a && g.vec_b && (g.K % X3_BK) == 0 && (kext % X3_BK) == 0 && g.M >= 4 && g.N >= 4;
+    const bool ak = g.sak == 1, bk = g.sbk == 1;
+    if (ok && (ak || g.sam == 1) && (bk || g.sbn == 1)) {
+      dim3 block(256);
+      if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 1>), grid, block, 0, st, g);
+      else if (ak && !bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 0>), grid, block, 0, st, g);
+      else if (!ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<0, 1>), grid, block, 0, st, g);
+      else hipLaunchKernelGGL((gemm_x3_kernel<0, 0>), grid, block, 0, st, g);
+      return;
+    }
+  }
   // measured on MI355X (scripts/gemm_f32_bench.py): split-K grids (many resident workgroups) are fastest at
   // BK 16, single-pass grids (<= a few hundred workgroups, latency hidden inside the workgroup) at BK 32
   const int bk = g_f32_bk_fwd() ? g_f32_bk_fwd() : (g.k_chunk ? 16 : 32);

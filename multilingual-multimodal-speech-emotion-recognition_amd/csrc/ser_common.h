@@ -62,6 +62,18 @@ SER_DEVFN void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
   lo = f2bf(x - bf2f(hi));
 }
 
+// two fp32 -> packed split planes with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even):
+// hi = {bf16(a), bf16(b)}, lo = {bf16(a - hi_a), bf16(b - hi_b)}; low half = first element
+typedef __attribute__((ext_vector_type(2))) __bf16 ser_bf16x2;
+SER_DEVFN uint32_t pack_bf16x2(float a, float b) {
+  ser_bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(uint32_t, v);
+}
+SER_DEVFN void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
 SER_DEVFN float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 SER_DEVFN float wave_sum(float v) {
