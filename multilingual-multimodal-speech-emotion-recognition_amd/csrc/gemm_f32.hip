@@ -483,13 +483,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, const float* 
 // gemm_f32_kernel.  64x64 tile, BK = 32; LDS planes are [row][32 bf16] with the 16-byte chunk index XORed by
 // 2*bit3(row) (conflict-free ds_read_b128 fragments).
 // ------------------------------------------------------------------------------------------
-constexpr int X3_BK = 32;
-SER_DEVFN int x3_off(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 3) & 1) << 1)) << 4); }
+constexpr int X3_BK = 64;
+// LDS plane = 64 rows x 128 B (64 bf16); 16-byte chunk index XOR (row & 7): conflict-free ds_read_b128 fragments
+SER_DEVFN int x3_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 template <int AKF, int BKF>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
-  constexpr int PLANE = 64 * 64;                     // bytes: 64 rows x 32 bf16
-  __shared__ __attribute__((aligned(16))) char lds[2][4 * PLANE];   // [stage][A_hi, A_lo, B_hi, B_lo]
+  constexpr int PLANE = 64 * 128;                    // bytes
+  __shared__ __attribute__((aligned(16))) char lds[2][4 * PLANE];   // [stage][A_hi, A_lo, B_hi, B_lo] = 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -506,14 +507,14 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[2], rb[2];
+  float4 ra[4], rb[4];      // 8 x 16-byte loads in flight per lane: one k-tile of latency per 64 k, not per 16
   auto load = [&](int k0) {
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < 4; ++e) {
       const int gi = tid + 256 * e;
-      if (AKF) { const int r = min(m0 + gi / 8, g.M - 1), k = (gi % 8) * 4; ra[e] = *(const float4*)(g.a + (long long)r * g.sam + k0 + k); }
+      if (AKF) { const int r = min(m0 + gi / 16, g.M - 1), k = (gi % 16) * 4; ra[e] = *(const float4*)(g.a + (long long)r * g.sam + k0 + k); }
       else { const int k = gi / 16, r = min(m0 + (gi % 16) * 4, g.M - 4); ra[e] = *(const float4*)(g.a + (long long)(k0 + k) * g.sak + r); }
-      if (BKF) { const int r = min(n0 + gi / 8, g.N - 1), k = (gi % 8) * 4; rb[e] = *(const float4*)(g.b + (long long)r * g.sbn + k0 + k); }
+      if (BKF) { const int r = min(n0 + gi / 16, g.N - 1), k = (gi % 16) * 4; rb[e] = *(const float4*)(g.b + (long long)r * g.sbn + k0 + k); }
       else { const int k = gi / 16, r = min(n0 + (gi % 16) * 4, g.N - 4); rb[e] = *(const float4*)(g.b + (long long)(k0 + k) * g.sbk + r); }
     }
   };
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
     split_bf16x2(v.x, v.y, h0, l0);
     split_bf16x2(v.z, v.w, h1, l1);
     if (kf) {
-      const int r = gi / 8, k = (gi % 8) * 4;
+      const int r = gi / 16, k = (gi % 16) * 4;
       const int off = x3_off(r, k >> 3) + (k & 7) * 2;
       *(uint2*)(hi + off) = make_uint2(h0, h1);
       *(uint2*)(lo + off) = make_uint2(l0, l1);
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
   auto store = [&](int buf) {
     char* s = lds[buf];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < 4; ++e) {
       store_one(s, s + PLANE, ra[e], tid + 256 * e, AKF != 0);
       store_one(s + 2 * PLANE, s + 3 * PLANE, rb[e], tid + 256 * e, BKF != 0);
     }
@@ -557,33 +558,36 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
     const char* s = lds[cur];
     if (want_rowsum) {
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
+      for (int ch = 0; ch < 8; ++ch) {
         const bf16x8 h = *(const bf16x8*)(s + x3_off(tid, ch)), l = *(const bf16x8*)(s + PLANE + x3_off(tid, ch));
 #pragma unroll
         for (int e = 0; e < 8; ++e) rowsum += bf2f((bf16_t)h[e]) + bf2f((bf16_t)l[e]);
       }
     }
-    bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = x3_off(wm * 32 + i * 16 + fr, fq);
-      ah[i] = *(const bf16x8*)(s + off);
-      al[i] = *(const bf16x8*)(s + PLANE + off);
-    }
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int off = x3_off(wn * 32 + j * 16 + fr, fq);
-      bh[j] = *(const bf16x8*)(s + 2 * PLANE + off);
-      bl[j] = *(const bf16x8*)(s + 3 * PLANE + off);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        const int off = x3_off(wm * 32 + i * 16 + fr, ks * 4 + fq);
+        ah[i] = *(const bf16x8*)(s + off);
+        al[i] = *(const bf16x8*)(s + PLANE + off);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        const int off = x3_off(wn * 32 + j * 16 + fr, ks * 4 + fq);
+        bh[j] = *(const bf16x8*)(s + 2 * PLANE + off);
+        bl[j] = *(const bf16x8*)(s + 3 * PLANE + off);
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
     if (kt + 1 < nk) store(cur ^ 1);
     __syncthreads();
   }
