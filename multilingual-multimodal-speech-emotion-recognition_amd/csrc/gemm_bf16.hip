@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
   constexpr int STAGE = (A_TILE + W_TILE) * NPL;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
   constexpr int EPI_BYTES = BM * (BN + 4) * 4;        // fp32 tile staged for the coalesced epilogue
-  constexpr int LDS_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  constexpr int LDS_RAW = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
+  // GEMMs on another stream, and a small workgroup that cannot get LDS waits for a whole GEMM workgroup to retire
+  constexpr int LDS_BYTES = LDS_RAW <= 32 * 1024 ? 34 * 1024 : LDS_RAW;
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;

@@ -185,7 +185,9 @@ __global__ __launch_bounds__(LN2_WAVES * 64) void ln2_bwd_kernel(const float* __
                                                       float* __restrict__ dx, float* __restrict__ dg1,
                                                       float* __restrict__ db1, float* __restrict__ dg2,
                                                       float* __restrict__ db2, int accumulate) {
-  __shared__ float4 red[LN2_WAVES][4][NV * 64];    // [wave][which param][chunk]
+  // 16 KB: small on purpose — this kernel runs beside the encoder GEMMs of the next batch, which leave little LDS
+  // free per CU; a workgroup that asks for more waits for a GEMM workgroup to retire
+  __shared__ float4 red[LN2_WAVES][NV * 64];       // [wave][chunk], reused for the four parameters in turn
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nchunk = D >> 2;
   float4 ag1[NV], ab1[NV], ag2[NV], ab2[NV];
@@ -252,24 +254,25 @@ __global__ __launch_bounds__(LN2_WAVES * 64) void ln2_bwd_kernel(const float* __
     }
   }
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    red[w][0][lane + 64 * i] = ag1[i]; red[w][1][lane + 64 * i] = ab1[i];
-    red[w][2][lane + 64 * i] = ag2[i]; red[w][3][lane + 64 * i] = ab2[i];
-  }
-  __syncthreads();
-  if (w >= 4) return;
-  float* out = w == 0 ? dg1 : (w == 1 ? db1 : (w == 2 ? dg2 : db2));   // wave w finishes parameter w
+  for (int which = 0; which < 4; ++which) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nchunk) {
-      float4 t = red[0][w][c];
+    for (int i = 0; i < NV; ++i)
+      red[w][lane + 64 * i] = which == 0 ? ag1[i] : (which == 1 ? ab1[i] : (which == 2 ? ag2[i] : ab2[i]));
+    __syncthreads();
+    float* out = which == 0 ? dg1 : (which == 1 ? db1 : (which == 2 ? dg2 : db2));
+    // waves 0..NV-1 each finish one 64-chunk slice of this parameter
+    if (w < NV) {
+      const int c = lane + 64 * w;
+      if (c < nchunk) {
+        float4 t = red[0][c];
 #pragma unroll
-      for (int ww = 1; ww < LN2_WAVES; ++ww) { const float4 u = red[ww][w][c]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
-      float4* dst = (float4*)(out + c * 4);
-      if (accumulate) { const float4 old = *dst; t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w; }
-      *dst = t;
+        for (int ww = 1; ww < LN2_WAVES; ++ww) { const float4 u = red[ww][c]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
+        float4* dst = (float4*)(out + c * 4);
+        if (accumulate) { const float4 old = *dst; t.x += old.x; t.y += old.y; t.z += old.z; t.w += old.w; }
+        *dst = t;
+      }
     }
+    __syncthreads();
   }
 }
 
