@@ -522,6 +522,175 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// LDS-staged cross-attention core for S <= 256 on both sides (the 1-5 s clips of the path): K^T / V (forward) and
+// V^T / K / Q / dctx (backward) of one (clip, head) are staged once per workgroup and every global access is
+// coalesced.  Same math and same saved tensors (P, dS) as the generic kernels above, which remain the fallback
+// for longer sequences.
+// ------------------------------------------------------------------------------------------
+constexpr int XF_MAXS = 256, XF_HD = 32, XF_LD = XF_MAXS + 1;
+
+// grid (ceil(Sq/16), heads, B); 4 waves x 4 query rows
+__global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                             int ldk, const float* __restrict__ v, int ldv,
+                                                             const float* __restrict__ kmask, int Sq, int Sk, int heads,
+                                                             float* __restrict__ P, float* __restrict__ ctx, int ldc) {
+  __shared__ float Kt[XF_HD][XF_LD];       // K^T: [d][key]
+  __shared__ float Vs[XF_MAXS][XF_HD];     // V:   [key][d]
+  __shared__ float prow[4][XF_MAXS];
+  __shared__ float qrow[4][XF_HD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16;
+  const float scale = 1.0f / sqrtf((float)XF_HD);
+  for (int idx = tid; idx < Sk * XF_HD; idx += 256) {
+    const int j = idx >> 5, d = idx & 31;
+    Kt[d][j] = k[((long long)b * Sk + j) * ldk + h * XF_HD + d];
+    Vs[j][d] = v[((long long)b * Sk + j) * ldv + h * XF_HD + d];
+  }
+  __syncthreads();
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + w * 4 + r;
+    if (i >= Sq) break;                       // wave-uniform
+    if (lane < XF_HD) qrow[w][lane] = q[((long long)b * Sq + i) * ldq + h * XF_HD + lane] * scale;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float sc[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = lane + 64 * u;
+      float s = -INFINITY;
+      if (j < Sk && (!kmask || kmask[(long long)b * Sk + j] != 0.f)) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < XF_HD; ++d) acc = fmaf(qrow[w][d], Kt[d][j], acc);
+        s = acc;
+      }
+      sc[u] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    const float mu = mx == -INFINITY ? 0.f : mx;
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sc[u] = expf(sc[u] - mu); sum += sc[u]; }
+    sum = wave_sum(sum);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    float* Pr = P + (((long long)b * heads + h) * Sq + i) * Sk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = lane + 64 * u;
+      if (j < Sk) { const float p = sc[u] * inv; prow[w][j] = p; Pr[j] = p; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // ctx[d] = sum_j p_j V[j][d]: lanes 0-31 take even keys, 32-63 odd keys
+    const int d = lane & 31, par = lane >> 5;
+    float acc = 0.f;
+    for (int j = par; j < Sk; j += 2) acc = fmaf(prow[w][j], Vs[j][d], acc);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < XF_HD) ctx[((long long)b * Sq + i) * ldc + h * XF_HD + d] = acc;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// per query row: dP = dctx.V^T, dS = P (dP - sum P dP), dq = scale * dS K
+__global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ k,
+                                                               int ldk, const float* __restrict__ v, int ldv,
+                                                               const float* __restrict__ P, int Sq, int Sk, int heads,
+                                                               float* __restrict__ dS, float* __restrict__ dq, int ldq) {
+  __shared__ float Vt[XF_HD][XF_LD];       // V^T: [d][key]
+  __shared__ float Ks[XF_MAXS][XF_HD];     // K:   [key][d]
+  __shared__ float srow[4][XF_MAXS];
+  __shared__ float drow[4][XF_HD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16;
+  const float scale = 1.0f / sqrtf((float)XF_HD);
+  for (int idx = tid; idx < Sk * XF_HD; idx += 256) {
+    const int j = idx >> 5, d = idx & 31;
+    Vt[d][j] = v[((long long)b * Sk + j) * ldv + h * XF_HD + d];
+    Ks[j][d] = k[((long long)b * Sk + j) * ldk + h * XF_HD + d];
+  }
+  __syncthreads();
+  for (int r = 0; r < 4; ++r) {
+    const int i = i0 + w * 4 + r;
+    if (i >= Sq) break;
+    if (lane < XF_HD) drow[w][lane] = dctx[((long long)b * Sq + i) * ldc + h * XF_HD + lane];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const float* Pr = P + (((long long)b * heads + h) * Sq + i) * Sk;
+    float dp[4], pp[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = lane + 64 * u;
+      dp[u] = 0.f; pp[u] = 0.f;
+      if (j < Sk) {
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < XF_HD; ++d) acc = fmaf(drow[w][d], Vt[d][j], acc);
+        dp[u] = acc; pp[u] = Pr[j];
+        dot = fmaf(pp[u], acc, dot);
+      }
+    }
+    dot = wave_sum(dot);
+    float* dSr = dS + (((long long)b * heads + h) * Sq + i) * Sk;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = lane + 64 * u;
+      if (j < Sk) { const float gg = pp[u] * (dp[u] - dot); srow[w][j] = gg; dSr[j] = gg; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int d = lane & 31, par = lane >> 5;
+    float acc = 0.f;
+    for (int j = par; j < Sk; j += 2) acc = fmaf(srow[w][j], Ks[j][d], acc);
+    acc += __shfl_xor(acc, 32, 64);
+    if (lane < XF_HD) dq[((long long)b * Sq + i) * ldq + h * XF_HD + d] = acc * scale;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// per key: dk_j = scale * sum_i dS_ij q_i ; dv_j = sum_i P_ij dctx_i.  grid (ceil(Sk/64), heads, B), one key per lane
+// of wave 0..: 256 threads = 4 waves, wave w handles the d-range [8w, 8w+8) for all 64 keys of the tile.
+__global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ q,
+                                                                int ldq, const float* __restrict__ P, const float* __restrict__ dS,
+                                                                int Sq, int Sk, int heads, float* __restrict__ dk, int ldk,
+                                                                float* __restrict__ dv, int ldv) {
+  __shared__ float Qs[XF_MAXS][XF_HD];
+  __shared__ float Ds[XF_MAXS][XF_HD];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y, j = blockIdx.x * 64 + lane;
+  const float scale = 1.0f / sqrtf((float)XF_HD);
+  for (int idx = tid; idx < Sq * XF_HD; idx += 256) {
+    const int i = idx >> 5, d = idx & 31;
+    Qs[i][d] = q[((long long)b * Sq + i) * ldq + h * XF_HD + d];
+    Ds[i][d] = dctx[((long long)b * Sq + i) * ldc + h * XF_HD + d];
+  }
+  __syncthreads();
+  const float* Pc = P + ((long long)b * heads + h) * Sq * Sk;
+  const float* Sc = dS + ((long long)b * heads + h) * Sq * Sk;
+  float ak[8], av[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ak[e] = av[e] = 0.f;
+  const int jj = j < Sk ? j : Sk - 1;
+  for (int i = 0; i < Sq; ++i) {
+    const float p = Pc[(long long)i * Sk + jj], s = Sc[(long long)i * Sk + jj];     // coalesced over the 64 keys
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      ak[e] = fmaf(s, Qs[i][w * 8 + e], ak[e]);       // LDS broadcast reads
+      av[e] = fmaf(p, Ds[i][w * 8 + e], av[e]);
+    }
+  }
+  if (j < Sk) {
+    float* dkr = dk + ((long long)b * Sk + j) * ldk + h * XF_HD + w * 8;
+    float* dvr = dv + ((long long)b * Sk + j) * ldv + h * XF_HD + w * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dkr[e] = ak[e] * scale; dvr[e] = av[e]; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // attentive statistics pooling core (ref src/models/pooling.py:21-28)
 // ------------------------------------------------------------------------------------------
@@ -1007,6 +1176,12 @@ extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, c
   SER_REQUIRE(Sk <= XA_MAXK && head_dim <= 64 && head_dim > 0, "xattn: Sk=%d (max %d) head_dim=%d (max 64)", Sk, XA_MAXK, head_dim);
   const long long rows = (long long)B * heads * Sq;
   if (rows <= 0) return SER_OK;
+  if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
+    hipLaunchKernelGGL(xattn_fwd_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
+                       v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
   hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
                      ldv, key_mask, B, Sq, Sk, heads, head_dim, P, ctx, ldc);
   SER_LAUNCH_CHECK();
@@ -1020,6 +1195,14 @@ extern "C" int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq
   hipStream_t st = (hipStream_t)stream;
   const long long rq = (long long)B * heads * Sq, rk = (long long)B * heads * Sk;
   if (rq <= 0 || rk <= 0) return SER_OK;
+  if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
+    hipLaunchKernelGGL(xattn_bwd_q_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
+                       Sq, Sk, heads, dS, dq, lddq);
+    hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, P, dS, Sq,
+                       Sk, heads, dk, lddk, dv, lddv);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
   hipLaunchKernelGGL(xattn_bwd_q_kernel, dim3((unsigned)((rq + 3) / 4)), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P, B, Sq,
                      Sk, heads, head_dim, dS, dq, lddq);
   hipLaunchKernelGGL(xattn_bwd_kv_kernel, dim3((unsigned)((rk + 3) / 4)), dim3(256), 0, st, dctx, ldc, q, ldq, P, dS, B, Sq, Sk,

@@ -182,3 +182,31 @@ def test_gemm_f32_three_forms(M, M_, N, K):
     ref = 2 * (dy.double().t() @ x.double())
     _close(dW, ref.float(), atol=3e-5 * float(ref.abs().max()), rtol=2e-4)
     _close(db, 2 * dy.double().sum(0).float(), atol=1e-5 * M_ ** 0.5 * 4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("Sq,Sk", [(199, 32), (32, 199), (300, 40), (40, 300), (7, 256), (256, 5)])
+def test_xattn_core_fast_and_generic_paths(M, Sq, Sk):
+    """softmax(QK^T/sqrt(d) + mask) V and its backward: S <= 256 runs the LDS-staged kernels, longer sequences the
+    generic ones; both against an fp64 autograd reference."""
+    from ser_amd import _ops as O
+    B, heads, hd = 2, 4, 32
+    E = heads * hd
+    g = torch.Generator().manual_seed(Sq * 1000 + Sk)
+    q, k, v = (torch.randn(B * n, E, generator=g) for n in (Sq, Sk, Sk))
+    mask = torch.ones(B, Sk)
+    mask[1, max(1, Sk // 2):] = 0
+    dctx = torch.randn(B * Sq, E, generator=g)
+    ctx, P = O.xattn_fwd(q.cuda(), k.cuda(), v.cuda(), mask.cuda(), B, Sq, Sk, heads)
+    dq, dk, dv = O.xattn_bwd(dctx.cuda(), q.cuda(), k.cuda(), v.cuda(), P, B, Sq, Sk, heads)
+    qd, kd, vd = (t_.double().requires_grad_() for t_ in (q, k, v))
+    qh = qd.view(B, Sq, heads, hd).transpose(1, 2)
+    kh = kd.view(B, Sk, heads, hd).transpose(1, 2)
+    vh = vd.view(B, Sk, heads, hd).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) / hd ** 0.5
+    s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B * Sq, E)
+    ref.backward(dctx.double())
+    _close(ctx, ref.detach().float(), atol=2e-5, rtol=1e-4)
+    _close(dq, qd.grad.float(), atol=5e-5, rtol=1e-3)
+    _close(dk, kd.grad.float(), atol=5e-5, rtol=1e-3)
+    _close(dv, vd.grad.float(), atol=5e-5, rtol=1e-3)
