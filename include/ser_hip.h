@@ -174,6 +174,11 @@ int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, l
  * folds the bias gradient (column sums of dy) into the same pass. */
 int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
                    float* y, int M, int N, int K, void* stream);
+/* first half of a classifier residual block in one launch (M <= 16, K <= 512):
+ * x1 = LN(x; g1,b1), u = LN(x1; g2,b2), y = act(u W^T + bias); x1, u and stats[4][M] are written for backward. */
+int ser_linear_fwd_ln2(const float* x, const float* W, const float* bias, int act, const float* g1, const float* b1,
+                       const float* g2, const float* b2, float eps, float* y1, float* y2, float* stats, float* y,
+                       int M, int N, int K, void* stream);
 /* relu_mask (may be NULL): the ReLU OUTPUT of the layer that produced x; when given, dx is multiplied by
  * relu'(mask), i.e. the activation backward is fused into the dgrad epilogue. */
 int ser_linear_dgrad(const float* dy, const float* W, const float* relu_mask, float* dx, int M, int N, int K,

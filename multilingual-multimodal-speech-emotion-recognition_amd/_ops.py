@@ -89,6 +89,19 @@ def ln2_fwd(x, g1, b1, g2, b2, eps=1e-5):
     return y1, y2, stats
 
 
+def linear_fwd_ln2(x, W, b, act, g1, b1, g2, b2, eps=1e-5):
+    """y = act(LN(LN(x;g1,b1);g2,b2) W^T + b) in one launch (M <= 16, K <= 512) -> y, x1, u, stats[4, M]."""
+    M, K = x.shape
+    N = W.shape[0]
+    y = empty(M, N, like=x)
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    stats = empty(4, M, like=x)
+    L.check(L.lib.ser_linear_fwd_ln2(L.ptr(x), L.ptr(W), L.ptr(b), act, L.ptr(g1), L.ptr(b1), L.ptr(g2), L.ptr(b2), eps,
+                                     L.ptr(y1), L.ptr(y2), L.ptr(stats), L.ptr(y), M, N, K, L.stream_ptr()),
+            "ser_linear_fwd_ln2")
+    return y, y1, y2, stats
+
+
 def ln2_bwd(du, dres, x, y1, stats, g1, g2, dg1, db1, dg2, db2, accumulate=False):
     """dx = LN1'(LN2'(du) + dres) and the four parameter gradients in one launch."""
     rows, D = du.shape

@@ -283,6 +283,121 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_fwd_kernel(const float* __r
   }
 }
 
+
+// skinny forward with the two chained LayerNorms of a classifier block as prologue:
+//   x1 = LN(x; g1,b1), u = LN(x1; g2,b2), y = act(u W^T + bias)      (ref classifier.py:209-210 + block[0..2])
+// Every workgroup recomputes the row statistics of the <= 16 rows (16 x K floats, L2-resident); workgroup 0 also
+// writes x1, u and the statistics for the residual add and for backward.  Saves one launch per residual block.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_fwd_ln2_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                    const float* __restrict__ bias, int act,
+                                                                    const float* __restrict__ g1, const float* __restrict__ b1,
+                                                                    const float* __restrict__ g2, const float* __restrict__ b2,
+                                                                    float eps, float* __restrict__ y1, float* __restrict__ y2,
+                                                                    float* __restrict__ stats, float* __restrict__ y, int M,
+                                                                    int N, int K) {
+  __shared__ float red[WAVES][64][4];
+  __shared__ float st[16][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nch4 = K >> 2;                           // float4 chunks per row (K <= 512 -> <= 2 per lane)
+  for (int row = w; row < 16; row += WAVES) {        // prologue: statistics of both LayerNorms, one wave per row
+    const int rr = min(row, M - 1);
+    float4 v[2];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = lane + 64 * e;
+      v[e] = c < nch4 ? *(const float4*)(x + (long long)rr * K + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const float* gp = pass == 0 ? g1 : g2;
+      const float* bp = pass == 0 ? b1 : b2;
+      const float mean = wave_sum(s) / (float)K;
+      float qq = 0.f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        if (lane + 64 * e < nch4) {
+          const float a = v[e].x - mean, b = v[e].y - mean, c2 = v[e].z - mean, d = v[e].w - mean;
+          qq += (a * a + b * b) + (c2 * c2 + d * d);
+        }
+      const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)K + eps);
+      if (lane == 0) { st[row][2 * pass] = mean; st[row][2 * pass + 1] = rstd; }
+      s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = lane + 64 * e;
+        if (c < nch4) {
+          const float4 gm = *(const float4*)(gp + c * 4), bt = *(const float4*)(bp + c * 4);
+          float4 o;
+          o.x = (v[e].x - mean) * rstd * gm.x + bt.x; o.y = (v[e].y - mean) * rstd * gm.y + bt.y;
+          o.z = (v[e].z - mean) * rstd * gm.z + bt.z; o.w = (v[e].w - mean) * rstd * gm.w + bt.w;
+          if (blockIdx.x == 0 && row < M) *(float4*)((pass == 0 ? y1 : y2) + (long long)row * K + c * 4) = o;
+          v[e] = o;
+          s += (o.x + o.y) + (o.z + o.w);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const int row = threadIdx.x >> 2, which = threadIdx.x & 3;
+    if (row < M) stats[which * M + row] = st[row][which];
+  }
+  const float m1 = st[i][0], r1 = st[i][1], m2 = st[i][2], r2 = st[i][3];
+  const float* xr = x + (long long)min(i, M - 1) * K + q * 4;
+  const float* wr = W + (long long)min(n0 + i, N - 1) * K + q * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int nchunk = K >> 4;
+  const int nit = (nchunk - w + WAVES - 1) / WAVES;
+  for (int it = 0; it < nit; it += 4) {
+    float4 a[4], b[4], G1[4], B1[4], G2[4], B2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = min(w + (it + u) * WAVES, nchunk - 1);
+      const int ko = c * 16 + q * 4;
+      a[u] = *(const float4*)(xr + c * 16);
+      b[u] = *(const float4*)(wr + c * 16);
+      G1[u] = *(const float4*)(g1 + ko); B1[u] = *(const float4*)(b1 + ko);
+      G2[u] = *(const float4*)(g2 + ko); B2[u] = *(const float4*)(b2 + ko);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float4 t;
+      t.x = (((a[u].x - m1) * r1 * G1[u].x + B1[u].x) - m2) * r2 * G2[u].x + B2[u].x;
+      t.y = (((a[u].y - m1) * r1 * G1[u].y + B1[u].y) - m2) * r2 * G2[u].y + B2[u].y;
+      t.z = (((a[u].z - m1) * r1 * G1[u].z + B1[u].z) - m2) * r2 * G2[u].z + B2[u].z;
+      t.w = (((a[u].w - m1) * r1 * G1[u].w + B1[u].w) - m2) * r2 * G2[u].w + B2[u].w;
+      if (it + u >= nit) t = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, b[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, b[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, b[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, b[u].w, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+  __syncthreads();
+  if (w == 0) {
+    const int n = n0 + i;
+    if (n < N) {
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < WAVES; ++ww) v += red[ww][lane][r];
+        y[(long long)m * N + n] = act_f32(v + bv, act);
+      }
+    }
+  }
+}
+
 // dx[M,Kc] = (dy[M,N] . W[N,Kc]) * relu'(mask)   (reduction over N split across the waves; mask = the
 // ReLU OUTPUT of the layer below, or NULL: fuses the activation backward into the dgrad epilogue)
 template <int WAVES>
@@ -715,6 +830,19 @@ extern "C" int ser_linear_fwd(const float* x, const float* W, const float* bias,
     return SER_OK;
   }
   return ser_gemm_f32(x, K, 1, W, 1, K, M, N, K, bias, act, residual, ldr, y, N, 0, stream);
+}
+
+// y = act(LN(LN(x; g1,b1); g2,b2) W^T + bias) with x1, u and the LayerNorm statistics written out (M <= 16, K <= 512)
+extern "C" int ser_linear_fwd_ln2(const float* x, const float* W, const float* bias, int act, const float* g1,
+                                  const float* b1, const float* g2, const float* b2, float eps, float* y1, float* y2,
+                                  float* stats, float* y, int M, int N, int K, void* stream) {
+  SER_REQUIRE(M > 0 && M <= 16 && K % 16 == 0 && K <= 512 && N > 0, "linear_fwd_ln2: needs M <= 16, K %% 16 == 0, K <= 512");
+  SER_REQUIRE(aligned16(x) && aligned16(W) && aligned16(g1) && aligned16(b1) && aligned16(g2) && aligned16(b2) &&
+                  aligned16(y1) && aligned16(y2), "linear_fwd_ln2: unaligned operand");
+  hipLaunchKernelGGL(skinny_fwd_ln2_kernel<8>, dim3(ceil_div(N, 16)), dim3(512), 0, (hipStream_t)stream, x, W, bias, act, g1, b1,
+                     g2, b2, eps, y1, y2, stats, y, M, N, K);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
 }
 
 // dx[M,K] (+)= dy[M,N] W[N,K]

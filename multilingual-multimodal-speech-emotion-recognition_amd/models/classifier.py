@@ -78,14 +78,20 @@ class _ClassifierFn(torch.autograd.Function):
         for blk, lno in zip(dc.residual_layers, dc.layer_norms):
             b = blk.block
             hin = h
-            if fused_ln:
+            if fused_ln and hin.shape[0] <= 16 and hin.shape[1] % 16 == 0:
+                # LN_out + LN_in + Linear + ReLU of the block in one launch
+                a, x1, u, stats = O.linear_fwd_ln2(hin, b[1].weight, b[1].bias, O.ACT_RELU, lno.weight, lno.bias,
+                                                   b[0].weight, b[0].bias)
+                lnA = lnB = None
+            elif fused_ln:
                 x1, u, stats = O.ln2_fwd(hin, lno.weight, lno.bias, b[0].weight, b[0].bias)
                 lnA = lnB = None
+                a = O.linear_fwd(u, b[1].weight, b[1].bias, O.ACT_RELU)
             else:
                 x1, lnA = O.ln_fwd(hin, lno.weight, lno.bias)
                 u, lnB = O.ln_fwd(x1, b[0].weight, b[0].bias)
                 stats = None
-            a = O.linear_fwd(u, b[1].weight, b[1].bias, O.ACT_RELU)
+                a = O.linear_fwd(u, b[1].weight, b[1].bias, O.ACT_RELU)
             h = O.linear_fwd(a, b[4].weight, b[4].bias, residual=x1)
             blocks.append((lnA, lnB, u, a, hin, x1, stats))
         tf = O.linear_fwd(h, op[0].weight, op[0].bias)
