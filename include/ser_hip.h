@@ -174,6 +174,9 @@ int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, l
  * folds the bias gradient (column sums of dy) into the same pass. */
 int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
                    float* y, int M, int N, int K, void* stream);
+/* up to 80 skinny (M <= 16) weight gradients in one launch; ptrs = host array {dy, x, dW, db} per problem,
+ * dims = host array {N, K} per problem */
+int ser_linear_wgrad_batch(const void* const* ptrs, const int* dims, int nprob, int M, int accumulate, void* stream);
 /* first half of a classifier residual block in one launch (M <= 16, K <= 512):
  * x1 = LN(x; g1,b1), u = LN(x1; g2,b2), y = act(u W^T + bias); x1, u and stats[4][M] are written for backward. */
 int ser_linear_fwd_ln2(const float* x, const float* W, const float* bias, int act, const float* g1, const float* b1,

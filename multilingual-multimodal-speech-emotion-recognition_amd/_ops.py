@@ -79,6 +79,25 @@ def linear_wgrad_pair(dya, xa, dWa, dba, dyb, xb, dWb, dbb, accumulate=False):
                                             1 if accumulate else 0, L.stream_ptr()), "ser_linear_wgrad_pair")
 
 
+def linear_wgrad_batch(problems, accumulate=False):
+    """problems: list of (dy[M,N], x[M,K], dW[N,K], db[N] or None), all with the same M <= 16 -> one launch per 80."""
+    import ctypes as C
+    M = problems[0][0].shape[0]
+    if M > 16:
+        for dy, x, dW, db in problems:
+            linear_wgrad(dy, x, dW, db, accumulate)
+        return
+    for s0 in range(0, len(problems), 80):
+        chunk = problems[s0:s0 + 80]
+        ptrs = (C.c_void_p * (4 * len(chunk)))()
+        dims = (C.c_int * (2 * len(chunk)))()
+        for i, (dy, x, dW, db) in enumerate(chunk):
+            ptrs[4 * i], ptrs[4 * i + 1], ptrs[4 * i + 2], ptrs[4 * i + 3] = L.ptr(dy), L.ptr(x), L.ptr(dW), L.ptr(db)
+            dims[2 * i], dims[2 * i + 1] = dy.shape[1], x.shape[1]
+        L.check(L.lib.ser_linear_wgrad_batch(ptrs, dims, len(chunk), M, 1 if accumulate else 0, L.stream_ptr()),
+                "ser_linear_wgrad_batch")
+
+
 def ln2_fwd(x, g1, b1, g2, b2, eps=1e-5):
     """y1 = LN(x; g1,b1), y2 = LN(y1; g2,b2) in one launch -> y1, y2, stats[4, rows]."""
     rows, D = x.shape

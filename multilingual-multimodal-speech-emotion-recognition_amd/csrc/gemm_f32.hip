@@ -731,6 +731,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
 
 }  // namespace
 
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 static int g_f32_bk = 0;   // 0 = automatic
 static int g_f32_bk_fwd() { return g_f32_bk; }
 extern "C" int ser_debug_set_f32_bk(int bk) { g_f32_bk = bk; return 0; }
@@ -814,7 +816,7 @@ extern "C" int ser_gemm_f32(const float* a, long long sam, long long sak, const 
   return ser_launch_gemm_f32(g, (hipStream_t)stream);
 }
 
-static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
 
 // y[M,N] = act(x[M,K] W[N,K]^T + b) + residual
 extern "C" int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
@@ -869,6 +871,83 @@ extern "C" int ser_linear_dgrad(const float* dy, const float* W, const float* re
     SER_REQUIRE(!accumulate, "linear_dgrad: relu_mask with accumulate needs the skinny path");
     return ser_act_bwd(dx, relu_mask, SER_ACT_RELU, (long long)M * K, dx, stream);
   }
+  return SER_OK;
+}
+
+// Up to SER_WGRAD_BATCH skinny weight gradients in ONE launch (problem index = blockIdx.z): the 70 weight gradients
+// of the classifier's residual stack feed nothing but the optimizer, so they are collected during backward and
+// issued together at its end instead of sitting, 35 launches deep, on the dgrad critical path.
+constexpr int SER_WGRAD_BATCH = 80;
+struct SkinnyWgradBatch {
+  SkinnyWgradArgs p[SER_WGRAD_BATCH];
+};
+__global__ __launch_bounds__(256) void skinny_wgrad_batch_kernel(const SkinnyWgradBatch bt, int M, int accumulate) {
+  const SkinnyWgradArgs& P = bt.p[blockIdx.z];
+  const float* __restrict__ dy = P.dy;
+  const float* __restrict__ x = P.x;
+  float* __restrict__ dW = P.dW;
+  float* __restrict__ db = P.db;
+  const int N = P.N, Kc = P.Kc;
+  if ((int)blockIdx.y * 64 >= N || (int)blockIdx.x * 64 >= Kc) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.y * 64 + w * 16;
+  const int c0 = blockIdx.x * 64 + 4 * i;
+  const bool cok = c0 < Kc, nok = n0 + i < N;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int m = 4 * s + q;
+    const bool mok = m < M;
+    const float a = (mok && nok) ? dy[(long long)m * N + n0 + i] : 0.f;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (mok && cok) b = *(const float4*)(x + (long long)m * Kc + c0);
+    asum += a;
+    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.y, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.z, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b.w, acc[3], 0, 0, 0);
+  }
+  if (cok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + q * 4 + r;
+      if (n >= N) continue;
+      float4* dst = (float4*)(dW + (long long)n * Kc + c0);
+      float4 o = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+      if (accumulate) { const float4 old = *dst; o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+      *dst = o;
+    }
+  }
+  if (db && blockIdx.x == 0) {
+    asum += __shfl_xor(asum, 16, 64);
+    asum += __shfl_xor(asum, 32, 64);
+    if (q == 0 && nok) db[n0 + i] = accumulate ? db[n0 + i] + asum : asum;
+  }
+}
+
+// ptrs[4*i .. 4*i+3] = {dy, x, dW, db} of problem i (host array of device pointers), dims[2*i..] = {N, K}
+extern "C" int ser_linear_wgrad_batch(const void* const* ptrs, const int* dims, int nprob, int M, int accumulate,
+                                      void* stream) {
+  SER_REQUIRE(nprob > 0 && nprob <= SER_WGRAD_BATCH && M > 0 && M <= 16, "linear_wgrad_batch: nprob=%d (max %d), M=%d (max 16)",
+              nprob, SER_WGRAD_BATCH, M);
+  SkinnyWgradBatch bt;
+  int gx = 1, gy = 1;
+  for (int i = 0; i < nprob; ++i) {
+    SkinnyWgradArgs& a = bt.p[i];
+    a.dy = (const float*)ptrs[4 * i]; a.x = (const float*)ptrs[4 * i + 1];
+    a.dW = (float*)ptrs[4 * i + 2]; a.db = (float*)ptrs[4 * i + 3];
+    a.N = dims[2 * i]; a.Kc = dims[2 * i + 1];
+    SER_REQUIRE(a.Kc % 4 == 0 && aligned16(a.x) && aligned16(a.dW), "linear_wgrad_batch: problem %d unaligned", i);
+    gx = gx > ceil_div(a.Kc, 64) ? gx : ceil_div(a.Kc, 64);
+    gy = gy > ceil_div(a.N, 64) ? gy : ceil_div(a.N, 64);
+  }
+  for (int i = nprob; i < SER_WGRAD_BATCH; ++i) bt.p[i] = bt.p[0];
+  hipLaunchKernelGGL(skinny_wgrad_batch_kernel, dim3(gx, gy, nprob), dim3(256), 0, (hipStream_t)stream, bt, M, accumulate);
+  SER_LAUNCH_CHECK();
   return SER_OK;
 }
 

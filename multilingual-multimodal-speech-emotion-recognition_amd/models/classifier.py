@@ -136,12 +136,15 @@ class _ClassifierFn(torch.autograd.Function):
         dtf = O.ln_bwd(df, lnF, op[1].weight, g(op[1].weight), g(op[1].bias), acc)
         O.linear_wgrad(dtf, h_last, g(op[0].weight), g(op[0].bias), acc)
         dh = O.linear_dgrad(dtf, op[0].weight)
-        # residual stack, last block first
+        # residual stack, last block first.  The weight gradients are only collected here and issued in ONE batched
+        # launch after the loop: they are off the dgrad chain, which is the critical path of this backward.
+        wg = []
         for i in range(len(blocks) - 1, -1, -1):
             lnA, lnB, u, a, hin, x1, stats = blocks[i]
             b, lno = dc.residual_layers[i].block, dc.layer_norms[i]
             da = O.linear_dgrad(dh, b[4].weight, relu_mask=a)              # dgrad with ReLU' fused
-            O.linear_wgrad_pair(dh, a, g(b[4].weight), g(b[4].bias), da, u, g(b[1].weight), g(b[1].bias), acc)
+            wg.append((dh, a, g(b[4].weight), g(b[4].bias)))
+            wg.append((da, u, g(b[1].weight), g(b[1].bias)))
             du = O.linear_dgrad(da, b[1].weight)
             if stats is not None:
                 dh = O.ln2_bwd(du, dh, hin, x1, stats, lno.weight, b[0].weight, g(lno.weight), g(lno.bias), g(b[0].weight),
@@ -149,6 +152,7 @@ class _ClassifierFn(torch.autograd.Function):
             else:
                 dx1 = O.ln_bwd(du, lnB, b[0].weight, g(b[0].weight), g(b[0].bias), acc, dx_add=dh)
                 dh = O.ln_bwd(dx1, lnA, lno.weight, g(lno.weight), g(lno.bias), acc)
+        O.linear_wgrad_batch(wg, acc)
         # input projection
         O.act_bwd(dh, h0, O.ACT_RELU)
         dt0 = O.ln_bwd(dh, ln0, ip[1].weight, g(ip[1].weight), g(ip[1].bias), acc)
