@@ -174,6 +174,11 @@ int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, l
  * folds the bias gradient (column sums of dy) into the same pass. */
 int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
                    float* y, int M, int N, int K, void* stream);
+/* up to 32 token-level (M > 16) weight gradients, split over their token dimension, in one GEMM launch + one
+ * reduce launch; ptrs = host array {dy, x, dW, db} per problem, dims = host array {M, N, K} per problem */
+size_t ser_linear_wgrad_group_workspace_bytes(const int* dims, int nprob);
+int ser_linear_wgrad_group(const void* const* ptrs, const int* dims, int nprob, int accumulate, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* up to 80 skinny (M <= 16) weight gradients in one launch; ptrs = host array {dy, x, dW, db} per problem,
  * dims = host array {N, K} per problem */
 int ser_linear_wgrad_batch(const void* const* ptrs, const int* dims, int nprob, int M, int accumulate, void* stream);

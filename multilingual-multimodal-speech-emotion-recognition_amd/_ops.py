@@ -29,6 +29,59 @@ def _wgrad_scope(*tensors):
     return torch.cuda.stream(side)
 
 
+# Deferred weight gradients: inside `defer_wgrads()` every linear_wgrad / linear_wgrad_batch request is only recorded;
+# leaving the scope issues them as a few grouped launches (ser_linear_wgrad_group for token-level problems,
+# ser_linear_wgrad_batch for M <= 16).  Weight gradients feed nothing but the optimizer, so this takes ~120 launches
+# off the dgrad chains of backward.  Not used with the eager data-parallel hooks (a bucket must be complete when its
+# module's backward returns).
+_DEFER = {"active": False, "tok": [], "skinny": []}
+
+
+@contextlib.contextmanager
+def defer_wgrads(enable=True):
+    if not enable or _DEFER["active"]:
+        yield
+        return
+    _DEFER["active"] = True
+    try:
+        yield
+    finally:
+        _DEFER["active"] = False
+        flush_deferred_wgrads()
+
+
+def flush_deferred_wgrads():
+    import ctypes as C
+    tok, skinny = _DEFER["tok"], _DEFER["skinny"]
+    _DEFER["tok"], _DEFER["skinny"] = [], []
+    for acc in (False, True):
+        grp = [p for p in tok if p[4] == acc]
+        for s0 in range(0, len(grp), 32):
+            chunk = grp[s0:s0 + 32]
+            ptrs = (C.c_void_p * (4 * len(chunk)))()
+            dims = (C.c_int * (3 * len(chunk)))()
+            for i, (dy, x, dW, db, _) in enumerate(chunk):
+                ptrs[4 * i], ptrs[4 * i + 1], ptrs[4 * i + 2], ptrs[4 * i + 3] = L.ptr(dy), L.ptr(x), L.ptr(dW), L.ptr(db)
+                dims[3 * i], dims[3 * i + 1], dims[3 * i + 2] = dy.shape[0], dy.shape[1], x.shape[1]
+            nb = L.lib.ser_linear_wgrad_group_workspace_bytes(dims, len(chunk))
+            ws = torch.empty(nb, dtype=torch.uint8, device=chunk[0][0].device)
+            L.check(L.lib.ser_linear_wgrad_group(ptrs, dims, len(chunk), 1 if acc else 0, L.ptr(ws), nb, L.stream_ptr()),
+                    "ser_linear_wgrad_group")
+        sk = [p[:4] for p in skinny if p[4] == acc]
+        by_m = {}
+        for p in sk:
+            by_m.setdefault(p[0].shape[0], []).append(p)
+        for probs in by_m.values():
+            _wgrad_batch_now(probs, acc)
+
+
+def _groupable(dy, x, dW):
+    M, N = dy.shape
+    K = x.shape[1]
+    return (M > 16 and N >= 4 and K >= 4 and N % 4 == 0 and K % 4 == 0 and dy.data_ptr() % 16 == 0
+            and x.data_ptr() % 16 == 0 and dy.is_contiguous() and x.is_contiguous())
+
+
 def wgrad_join():
     """Make the current stream wait for every weight-gradient launch issued since the last join (capture only)."""
     if _WG["dirty"]:
@@ -69,7 +122,7 @@ def linear_dgrad(dy, W, out=None, accumulate=False, relu_mask=None):
 def linear_wgrad_pair(dya, xa, dWa, dba, dyb, xb, dWb, dbb, accumulate=False):
     """Two skinny (M <= 16) weight gradients + bias gradients in one launch."""
     M = dya.shape[0]
-    if M > 16:
+    if M > 16 or _DEFER["active"]:
         linear_wgrad(dya, xa, dWa, dba, accumulate)
         linear_wgrad(dyb, xb, dWb, dbb, accumulate)
         return
@@ -81,12 +134,17 @@ def linear_wgrad_pair(dya, xa, dWa, dba, dyb, xb, dWb, dbb, accumulate=False):
 
 def linear_wgrad_batch(problems, accumulate=False):
     """problems: list of (dy[M,N], x[M,K], dW[N,K], db[N] or None), all with the same M <= 16 -> one launch per 80."""
-    import ctypes as C
     M = problems[0][0].shape[0]
-    if M > 16:
+    if M > 16 or _DEFER["active"]:
         for dy, x, dW, db in problems:
             linear_wgrad(dy, x, dW, db, accumulate)
         return
+    _wgrad_batch_now(problems, accumulate)
+
+
+def _wgrad_batch_now(problems, accumulate):
+    import ctypes as C
+    M = problems[0][0].shape[0]
     for s0 in range(0, len(problems), 80):
         chunk = problems[s0:s0 + 80]
         ptrs = (C.c_void_p * (4 * len(chunk)))()
@@ -135,6 +193,13 @@ def linear_wgrad(dy, x, dW, db=None, accumulate=False):
     """dW[N,K] (+)= dy[M,N]^T x[M,K];  db[N] (+)= colsum(dy) in the same pass."""
     M, N = dy.shape
     K = x.shape[1]
+    if _DEFER["active"]:
+        if M <= 16 and K % 4 == 0:
+            _DEFER["skinny"].append((dy, x, dW, db, bool(accumulate)))
+            return
+        if _groupable(dy, x, dW):
+            _DEFER["tok"].append((dy, x, dW, db, bool(accumulate)))
+            return
     nbytes = L.lib.ser_linear_wgrad_workspace_bytes(M, N, K)
     with _wgrad_scope(dy, x):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device) if nbytes else None

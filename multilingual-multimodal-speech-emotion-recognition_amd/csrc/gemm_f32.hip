@@ -602,18 +602,19 @@ constexpr int X3_BK = 64;
 // LDS plane = 64 rows x 128 B (64 bf16); 16-byte chunk index XOR (row & 7): conflict-free ds_read_b128 fragments
 SER_DEVFN int x3_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
+constexpr int X3_PLANE = 64 * 128;                   // bytes
 template <int AKF, int BKF>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
-  constexpr int PLANE = 64 * 128;                    // bytes
-  __shared__ __attribute__((aligned(16))) char lds[2][4 * PLANE];   // [stage][A_hi, A_lo, B_hi, B_lo] = 64 KB
+SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, const int bz, char (*lds)[4 * X3_PLANE]) {
+  constexpr int PLANE = X3_PLANE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int m0 = by * 64, n0 = bx * 64;
   const int fr = lane & 15, fq = lane >> 4;
-  const int kbeg = g.k_chunk ? blockIdx.z * g.k_chunk : 0;
+  const int kbeg = g.k_chunk ? bz * g.k_chunk : 0;
   const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
-  const int nk = (kend - kbeg) / X3_BK;
-  const bool want_rowsum = g.ws_rowsum != nullptr && blockIdx.x == 0 && tid < 64;
+  const int nk = (kend - kbeg + X3_BK - 1) / X3_BK;   // a k tail (only row-contiguous operands, i.e. wgrad) is zero-filled
+  const bool has_tail = ((kend - kbeg) % X3_BK) != 0;
+  const bool want_rowsum = g.ws_rowsum != nullptr && bx == 0 && tid < 64;
   float rowsum = 0.f;
 
   f32x4 acc[2][2];
@@ -628,9 +629,9 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
     for (int e = 0; e < 4; ++e) {
       const int gi = tid + 256 * e;
       if (AKF) { const int r = min(m0 + gi / 16, g.M - 1), k = (gi % 16) * 4; ra[e] = *(const float4*)(g.a + (long long)r * g.sam + k0 + k); }
-      else { const int k = gi / 16, r = min(m0 + (gi % 16) * 4, g.M - 4); ra[e] = *(const float4*)(g.a + (long long)(k0 + k) * g.sak + r); }
+      else { const int k = min(k0 + gi / 16, kend - 1), r = min(m0 + (gi % 16) * 4, g.M - 4); ra[e] = *(const float4*)(g.a + (long long)k * g.sak + r); }
       if (BKF) { const int r = min(n0 + gi / 16, g.N - 1), k = (gi % 16) * 4; rb[e] = *(const float4*)(g.b + (long long)r * g.sbn + k0 + k); }
-      else { const int k = gi / 16, r = min(n0 + (gi % 16) * 4, g.N - 4); rb[e] = *(const float4*)(g.b + (long long)(k0 + k) * g.sbk + r); }
+      else { const int k = min(k0 + gi / 16, kend - 1), r = min(n0 + (gi % 16) * 4, g.N - 4); rb[e] = *(const float4*)(g.b + (long long)k * g.sbk + r); }
     }
   };
   auto store_one = [&](char* hi, char* lo, const float4 v, int gi, bool kf) {
@@ -655,8 +656,16 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
       *(uint16_t*)(lo + x3_off(r + 3, ch) + kb) = (uint16_t)(l1 >> 16);
     }
   };
-  auto store = [&](int buf) {
+  auto store = [&](int buf, int k0) {
     char* s = lds[buf];
+    if (has_tail && k0 + X3_BK > kend) {      // uniform: only the last k-tile of a ragged reduction
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + (tid + 256 * e) / 16;
+        if (!AKF && k >= kend) ra[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!BKF && k >= kend) rb[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       store_one(s, s + PLANE, ra[e], tid + 256 * e, AKF != 0);
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
   };
 
   load(kbeg);
-  store(0);
+  store(0, kbeg);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -703,12 +712,12 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) store(cur ^ 1);
+    if (kt + 1 < nk) store(cur ^ 1, kbeg + (kt + 1) * X3_BK);
     __syncthreads();
   }
 
-  if (want_rowsum && m0 + tid < g.M) g.ws_rowsum[(long long)blockIdx.z * g.M + m0 + tid] = rowsum;
-  float* wsz = g.ws ? g.ws + (long long)blockIdx.z * g.M * g.N : nullptr;
+  if (want_rowsum && m0 + tid < g.M) g.ws_rowsum[(long long)bz * g.M + m0 + tid] = rowsum;
+  float* wsz = g.ws ? g.ws + (long long)bz * g.M * g.N : nullptr;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + wn * 32 + j * 16 + fr;
@@ -726,6 +735,70 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
         float* cp = g.c + (long long)m * g.ldc + n;
         *cp = g.accumulate ? *cp + v : v;
       }
+  }
+}
+
+
+template <int AKF, int BKF>
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
+  __shared__ __attribute__((aligned(16))) char lds[2][4 * X3_PLANE];   // [stage][A_hi, A_lo, B_hi, B_lo] = 64 KB
+  x3_body<AKF, BKF>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// Grouped token-level weight gradients: up to 32 independent dW = dy^T x problems (split over their token
+// dimension) in ONE launch.  They feed only the optimizer, so the steppers collect them during backward and issue
+// them together at its end, off the dgrad critical path.
+constexpr int SER_WGRAD_GROUP = 32;
+struct WgradGroupProb {
+  const float *dy, *x;
+  float *ws, *ws_rowsum;
+  int M, N, K, z0, splits;
+};
+struct WgradGroup {
+  WgradGroupProb p[SER_WGRAD_GROUP];
+  int nprob;
+};
+__global__ __launch_bounds__(256) void gemm_x3_group_kernel(const WgradGroup G) {
+  __shared__ __attribute__((aligned(16))) char lds[2][4 * X3_PLANE];
+  int pi = 0;
+  for (int i = 1; i < G.nprob; ++i)
+    if ((int)blockIdx.z >= G.p[i].z0) pi = i;
+  const WgradGroupProb& P = G.p[pi];
+  if ((int)blockIdx.y * 64 >= P.N || (int)blockIdx.x * 64 >= P.K) return;
+  SerGemmF32Args g;
+  g.a = P.dy; g.b = P.x; g.c = nullptr; g.M = P.N; g.N = P.K; g.K = P.M;
+  g.sam = 1; g.sak = P.N; g.sbk = P.K; g.sbn = 1; g.ldc = P.K;
+  g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = 0;
+  g.k_chunk = 256; g.ws = P.ws; g.ws_rowsum = P.ws_rowsum; g.vec_a = g.vec_b = 1;
+  x3_body<0, 0>(g, blockIdx.x, blockIdx.y, (int)blockIdx.z - P.z0, lds);
+}
+
+struct ReduceGroupProb {
+  const float *ws, *ws_rowsum;
+  float *dW, *db;
+  int splits, N;
+  long long MN, off;
+};
+struct ReduceGroup {
+  ReduceGroupProb p[SER_WGRAD_GROUP];
+  int nprob;
+};
+__global__ void splitk_reduce_group_kernel(const ReduceGroup G, int accumulate) {
+  const long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int pi = 0;
+  for (int i = 1; i < G.nprob; ++i)
+    if (gi >= G.p[i].off) pi = i;
+  const ReduceGroupProb& P = G.p[pi];
+  const long long i = gi - P.off;
+  if (i < P.MN) {
+    float v = 0.f;
+    for (int z = 0; z < P.splits; ++z) v += P.ws[(long long)z * P.MN + i];
+    P.dW[i] = accumulate ? P.dW[i] + v : v;
+  }
+  if (P.db && i < P.N) {
+    float v = 0.f;
+    for (int z = 0; z < P.splits; ++z) v += P.ws_rowsum[(long long)z * P.N + i];
+    P.db[i] = accumulate ? P.db[i] + v : v;
   }
 }
 
@@ -754,8 +827,10 @@ extern "C" int ser_debug_set_head_x3(int v) { g_use_x3 = v; return 0; }
 static void launch_6464(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
   {
     const int kext = g.k_chunk ? g.k_chunk : g.K;
-    const bool ok = g_use_x3 && g.vec_a && g.vec_b && (g.K % X3_BK) == 0 && (kext % X3_BK) == 0 && g.M >= 4 && g.N >= 4;
     const bool ak = g.sak == 1, bk = g.sbk == 1;
+    // a ragged reduction length is supported when both operands are row-contiguous (the wgrad form)
+    const bool ktail_ok = (!ak && !bk) || ((g.K % X3_BK) == 0 && (kext % X3_BK) == 0);
+    const bool ok = g_use_x3 && g.vec_a && g.vec_b && ktail_ok && (!g.k_chunk || g.k_chunk % X3_BK == 0) && g.M >= 4 && g.N >= 4;
     if (ok && (ak || g.sam == 1) && (bk || g.sbn == 1)) {
       dim3 block(256);
       if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 1>), grid, block, 0, st, g);
@@ -927,6 +1002,56 @@ __global__ __launch_bounds__(256) void skinny_wgrad_batch_kernel(const SkinnyWgr
     asum += __shfl_xor(asum, 32, 64);
     if (q == 0 && nok) db[n0 + i] = accumulate ? db[n0 + i] + asum : asum;
   }
+}
+
+extern "C" size_t ser_linear_wgrad_group_workspace_bytes(const int* dims, int nprob) {
+  size_t total = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const int M = dims[3 * i], N = dims[3 * i + 1], K = dims[3 * i + 2];
+    const size_t splits = ceil_div(M, 256);
+    total += ((splits * N * K + splits * N) * sizeof(float) + 255) & ~(size_t)255;
+  }
+  return total + 256;
+}
+
+// ptrs[4*i..] = {dy[M,N], x[M,K], dW[N,K], db[N] or NULL}; dims[3*i..] = {M, N, K}; M > 16 rows (tokens)
+extern "C" int ser_linear_wgrad_group(const void* const* ptrs, const int* dims, int nprob, int accumulate, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SER_REQUIRE(nprob > 0 && nprob <= SER_WGRAD_GROUP, "linear_wgrad_group: nprob=%d (max %d)", nprob, SER_WGRAD_GROUP);
+  SER_REQUIRE(workspace && workspace_bytes >= ser_linear_wgrad_group_workspace_bytes(dims, nprob), "linear_wgrad_group: workspace too small");
+  WgradGroup G;
+  ReduceGroup R;
+  memset(&G, 0, sizeof(G));
+  memset(&R, 0, sizeof(R));
+  G.nprob = R.nprob = nprob;
+  char* wp = (char*)workspace;
+  int z = 0, gx = 1, gy = 1;
+  long long off = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const int M = dims[3 * i], N = dims[3 * i + 1], K = dims[3 * i + 2];
+    const float* dy = (const float*)ptrs[4 * i];
+    const float* x = (const float*)ptrs[4 * i + 1];
+    SER_REQUIRE(M > 16 && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0 && aligned16(dy) && aligned16(x),
+                "linear_wgrad_group: problem %d (M=%d N=%d K=%d) unsupported", i, M, N, K);
+    const int splits = ceil_div(M, 256);
+    WgradGroupProb& p = G.p[i];
+    p.dy = dy; p.x = x; p.M = M; p.N = N; p.K = K; p.z0 = z; p.splits = splits;
+    p.ws = (float*)wp;
+    p.ws_rowsum = ptrs[4 * i + 3] ? p.ws + (size_t)splits * N * K : nullptr;
+    wp += (((size_t)splits * N * K + (size_t)splits * N) * sizeof(float) + 255) & ~(size_t)255;
+    ReduceGroupProb& r = R.p[i];
+    r.ws = p.ws; r.ws_rowsum = p.ws_rowsum; r.dW = (float*)ptrs[4 * i + 2]; r.db = (float*)ptrs[4 * i + 3];
+    r.splits = splits; r.N = N; r.MN = (long long)N * K; r.off = off;
+    off += (r.MN + 255) / 256 * 256;
+    z += splits;
+    gx = gx > ceil_div(K, 64) ? gx : ceil_div(K, 64);
+    gy = gy > ceil_div(N, 64) ? gy : ceil_div(N, 64);
+  }
+  hipLaunchKernelGGL(gemm_x3_group_kernel, dim3(gx, gy, z), dim3(256), 0, st, G);
+  hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)(off / 256)), dim3(256), 0, st, R, accumulate);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
 }
 
 // ptrs[4*i .. 4*i+3] = {dy, x, dW, db} of problem i (host array of device pointers), dims[2*i..] = {N, K}

@@ -262,7 +262,9 @@ class TrainStepper:
 
     def _fwd_bwd(self, wave, ids, mask, labels):
         loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto)
-        loss.backward()
+        # eager data parallelism reduces a bucket from its module's backward hook, so gradients cannot be deferred there
+        with _ops.defer_wgrads(self.use_graph or self.reducer is None):
+            loss.backward()
         _ops.wgrad_join()
         return loss.detach(), logits.detach()
 
@@ -273,13 +275,15 @@ class TrainStepper:
         leaf = fused.detach().requires_grad_()
         logits, unc, _ = s.classifier(leaf, use_openmax=False, return_uncertainty=True)
         loss = s.criterion(logits, unc, leaf, s.prototypes.prototypes, labels, use_proto=self.use_proto)
-        loss.backward()
+        with _ops.defer_wgrads():
+            loss.backward()
         _ops.wgrad_join()
         self._fused, self._dfused = fused, leaf.grad
         return loss.detach(), logits.detach()
 
     def _bwd_b(self):
-        self._fused.backward(self._dfused)
+        with _ops.defer_wgrads():
+            self._fused.backward(self._dfused)
         _ops.wgrad_join()
         self._fused = self._dfused = None
 
@@ -385,7 +389,8 @@ class PipelinedStepper:
             for _ in range(2):
                 self.opt.zero_grad(set_to_none=True)
                 loss, _ = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
-                loss.backward()
+                with _ops.defer_wgrads():
+                    loss.backward()
             self.opt.prepare_step(dev)
             self.opt.t -= 1
             if self.opt._plan is None:
@@ -405,7 +410,8 @@ class PipelinedStepper:
         self.g_head = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_head):
             loss, logits = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
-            loss.backward()
+            with _ops.defer_wgrads():
+                loss.backward()
             _ops.wgrad_join()
             self.loss, self.logits = loss.detach(), logits.detach()
         self.g_opt = torch.cuda.CUDAGraph()
