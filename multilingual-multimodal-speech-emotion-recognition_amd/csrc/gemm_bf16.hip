@@ -54,17 +54,24 @@ SER_DEVFN float apply_act(float v, int act) {
 }
 
 template <int BM, int BN, bool X3>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) {
-  constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
-  constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
-  constexpr int STAGE = (A_TILE + W_TILE) * NPL;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int EPI_BYTES = BM * (BN + 4) * 4;        // fp32 tile staged for the coalesced epilogue
-  constexpr int LDS_RAW = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+struct GemmCfg {
+  static constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
+  static constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
+  static constexpr int STAGE = (A_TILE + W_TILE) * NPL;
+  static constexpr int EPI_BYTES = BM * (BN + 4) * 4;        // fp32 tile staged for the coalesced epilogue
+  static constexpr int LDS_RAW = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
   // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
   // GEMMs on another stream, and a small workgroup that cannot get LDS waits for a whole GEMM workgroup to retire
-  constexpr int LDS_BYTES = LDS_RAW <= 32 * 1024 ? 34 * 1024 : LDS_RAW;
-  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  static constexpr int LDS_BYTES = LDS_RAW <= 32 * 1024 ? 34 * 1024 : LDS_RAW;
+};
+
+// one output tile; `bid` = tile index inside the (clip, group) batch entry `bz`
+template <int BM, int BN, bool X3>
+SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, char* lds) {
+  constexpr int NPL = GemmCfg<BM, BN, X3>::NPL;
+  constexpr int A_TILE = GemmCfg<BM, BN, X3>::A_TILE, W_TILE = GemmCfg<BM, BN, X3>::W_TILE;
+  constexpr int STAGE = GemmCfg<BM, BN, X3>::STAGE;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   int tile_m, tile_n;
   {
-    const int nt = tiles_m * tiles_n, bid = blockIdx.x;
+    const int nt = tiles_m * tiles_n, bid = bid_in;
     const int q = nt >> 3, r = nt & 7, xcd = bid & 7, local = bid >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     constexpr int GROUP_M = 4;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
     tile_n = (t % per_group) / gsz;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int b1 = blockIdx.z / g.nb2, b2 = blockIdx.z % g.nb2;
+  const int b1 = bz / g.nb2, b2 = bz % g.nb2;
 
   const long long aoff = b1 * g.sa1 + b2 * g.sa2, woff = b1 * g.sw1 + b2 * g.sw2;
   const bf16_t* a_hi = g.a_hi + aoff;
@@ -227,18 +234,35 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g) 
   }
 }
 
+// Persistent launch: the grid never exceeds what is resident at once (gridDim.x <= 2 workgroups per CU), each
+// workgroup walks tiles `blockIdx.x, blockIdx.x + gridDim.x, ...` of the flattened (batch entry, tile) space.  No tile
+// ever waits in the dispatcher's queue, so the small head kernels of the other stream are placed as soon as they
+// arrive instead of behind this kernel's not-yet-dispatched workgroups.
+template <int BM, int BN, bool X3>
+__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3>::LDS_BYTES];
+  for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    gemm_tile<BM, BN, X3>(g, w % tiles, w / tiles, lds);
+    __syncthreads();     // the epilogue's LDS tile is dead before the next tile's first stage lands
+  }
+}
+
 // ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
 struct ProfRec {
   hipEvent_t e0, e1;
   double flops;
 };
+static int g_gemm_persist_cap = 0;   // 0 = one workgroup per tile; N = persistent grid of at most N workgroups
+extern "C" int ser_debug_set_gemm_persist(int cap) { g_gemm_persist_cap = cap; return 0; }
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
 template <int BM, int BN>
 int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-  dim3 grid(tiles, 1, g.nb1 * g.nb2), block(256);
+  const int total = tiles * g.nb1 * g.nb2;
+  const int cap = g_gemm_persist_cap > 0 ? g_gemm_persist_cap : total;
+  dim3 grid(total < cap ? total : cap), block(256);
   ProfRec rec;
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventCreate(&rec.e0));
@@ -247,9 +271,9 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
   if (g.a_lo && g.w_lo)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, 0, st, g, tiles, total);
   else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, 0, st, g);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, 0, st, g, tiles, total);
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventRecord(rec.e1, st));
     g_prof.push_back(rec);
