@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
+from .. import _ops as O
 from .._engines import Wav2Vec2Engine
 from .adapter import adapter_apply
 from .pooling import AttentiveStatsPooling
@@ -32,6 +33,59 @@ class _ProjectionHolder(nn.Module):
     def __init__(self, name, dim):
         super().__init__()
         setattr(self, name, nn.Sequential(nn.Linear(dim, 32), nn.ReLU(), nn.Dropout(0.1), nn.Linear(32, dim)))
+
+
+class _GateFusionFn(torch.autograd.Function):
+    """Learnable part of the gate path (ref audio_encoder.py:115-132): project the raw quality / conditioning
+    features (8->32->8, 12->32->12), broadcast over frames, concatenate with the sequence, Linear + ReLU."""
+
+    @staticmethod
+    def forward(ctx, owner, seq, q_raw, c_raw, *params):
+        B, S, H = seq.shape
+        feats, saved = [], []
+        for raw, holder, name in ((q_raw, getattr(owner, "quality_gates", None), "quality_projection"),
+                                  (c_raw, getattr(owner, "audio_conditioning", None), "conditioning_projection")):
+            if raw is None:
+                continue
+            proj = getattr(holder, name)
+            r2 = raw.to(seq.device, torch.float32).contiguous()
+            hdn = O.linear_fwd(r2, proj[0].weight, proj[0].bias, O.ACT_RELU)
+            feats.append(O.linear_fwd(hdn, proj[3].weight, proj[3].bias))
+            saved.append((proj, r2, hdn))
+        f = torch.cat(feats, dim=1)                                        # [B, 8 | 12 | 20]   (data movement only)
+        xin = torch.cat([seq, f[:, None, :].expand(B, S, f.shape[1])], dim=2).reshape(B * S, H + f.shape[1]).contiguous()
+        fus = owner._fusion_layer(q_raw is not None, c_raw is not None)
+        out = O.linear_fwd(xin, fus[0].weight, fus[0].bias, O.ACT_RELU)
+        ctx.owner, ctx.saved, ctx.dims, ctx.fus = owner, (xin, out, saved), (B, S, H, f.shape[1]), fus
+        ctx.need_dx = seq.requires_grad
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        owner, fus = ctx.owner, ctx.fus
+        xin, out, saved = ctx.saved
+        B, S, H, F = ctx.dims
+        fp = owner._gate_flat
+        acc, g = fp.accumulating(), fp.gview
+        d = O.act_bwd(dout.reshape(B * S, H).contiguous(), out, O.ACT_RELU, inplace=False)
+        O.linear_wgrad(d, xin, g(fus[0].weight), g(fus[0].bias), acc)
+        dxin = O.linear_dgrad(d, fus[0].weight)                            # [B*S, H+F]
+        dseq = dxin.view(B, S, H + F)[:, :, :H].contiguous() if ctx.need_dx else None
+        df = torch.empty(B, F, dtype=torch.float32, device=dxin.device)    # sum over the frames of each clip
+        for b in range(B):
+            L.check(L.lib.ser_colsum(dxin.data_ptr() + 4 * (b * S * (H + F) + H), S, F, H + F, df[b].data_ptr(), 0, L.stream_ptr()),
+                    "ser_colsum")
+        o = 0
+        for proj, r2, hdn in saved:
+            n = proj[3].weight.shape[0]
+            dfeat = df[:, o:o + n].contiguous()
+            o += n
+            O.linear_wgrad(dfeat, hdn, g(proj[3].weight), g(proj[3].bias), acc)
+            dh = O.linear_dgrad(dfeat, proj[3].weight, relu_mask=hdn)
+            O.linear_wgrad(dh, r2, g(proj[0].weight), g(proj[0].bias), acc)
+        fp.publish()
+        ctx.saved = None
+        return (None, dseq, None, None) + (None,) * len(fp.params)
 
 
 class AudioEncoder(nn.Module):
@@ -65,6 +119,7 @@ class AudioEncoder(nn.Module):
             self.combined_fusion = nn.Sequential(nn.Linear(hid + 20, hid), nn.ReLU(), nn.Dropout(0.1))
         self.precision = precision
         self._engine = None
+        self._gate_flat = None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_engine", None))
 
     def _apply(self, fn, *a, **k):
@@ -86,11 +141,33 @@ class AudioEncoder(nn.Module):
             seq = self.engine().forward(wave)
         return adapter_apply(self, seq)
 
-    def forward(self, audio_waveforms: List[torch.Tensor], texts: Optional[List[str]] = None):
-        if self.use_quality_gates or self.use_audio_conditioning:
+    def _fusion_layer(self, has_q, has_c):
+        return self.combined_fusion if (has_q and has_c) else (self.quality_fusion if has_q else self.conditioning_fusion)
+
+    def fuse_gate_features(self, seq, quality_raw=None, conditioning_raw=None):
+        """seq [B,S,H] + raw quality [B,8] / conditioning [B,12] features -> fused sequence (ref :115-132)."""
+        from ._flat import FlatParams
+        if self._gate_flat is None:
+            mods = []
+            if self.use_quality_gates:
+                mods += [self.quality_gates.quality_projection, self.quality_fusion]
+            if self.use_audio_conditioning:
+                mods += [self.audio_conditioning.conditioning_projection, self.conditioning_fusion]
+            if self.use_quality_gates and self.use_audio_conditioning:
+                mods += [self.combined_fusion]
+            self._gate_flat = FlatParams([p for m_ in mods for p in m_.parameters()])
+        self._gate_flat.ensure()
+        return _GateFusionFn.apply(self, seq, quality_raw, conditioning_raw, *self._gate_flat.params)
+
+    def forward(self, audio_waveforms: List[torch.Tensor], texts: Optional[List[str]] = None, gate_features=None):
+        """gate_features: (quality_raw [B,8] or None, conditioning_raw [B,12] or None) — the raw feature vectors the
+        reference's CPU DSP front end computes per clip (quality_gates.py:544-553, audio_conditioning.py:562-577).
+        Required when the gate flags are on: the DSP itself is not part of the HIP path (see module docstring)."""
+        gates_on = self.use_quality_gates or self.use_audio_conditioning
+        if gates_on and gate_features is None:
             raise NotImplementedError(
                 "the CPU DSP quality-gate / audio-conditioning front end is outside the HIP hot path; construct with "
-                "use_quality_gates=False, use_audio_conditioning=False")
+                "use_quality_gates=False, use_audio_conditioning=False, or pass gate_features=(quality_raw, conditioning_raw)")
         dev = self.adapter[0].weight.device
         if isinstance(audio_waveforms, torch.Tensor) and audio_waveforms.dim() == 2:
             groups = {int(audio_waveforms.shape[1]): (list(range(audio_waveforms.shape[0])), audio_waveforms.to(dev))}
@@ -111,5 +188,16 @@ class AudioEncoder(nn.Module):
             batch_seq = seq if list(groups.values())[0][0] == list(range(n)) else torch.stack(outs)
         else:   # zero-pad to the longest; the mask stays all-ones, exactly as the reference does (:140-166)
             batch_seq = torch.nn.utils.rnn.pad_sequence(outs, batch_first=True)
+        if gates_on:
+            q_raw, c_raw = gate_features
+            lens = [o_.shape[0] for o_ in outs]
+            if len(set(lens)) == 1:
+                batch_seq = self.fuse_gate_features(batch_seq, q_raw if self.use_quality_gates else None,
+                                                    c_raw if self.use_audio_conditioning else None)
+            else:   # the reference fuses each clip before padding (:129-132), so padded frames stay zero
+                fused = [self.fuse_gate_features(o_[None], None if q_raw is None or not self.use_quality_gates else q_raw[i:i + 1],
+                                                 None if c_raw is None or not self.use_audio_conditioning else c_raw[i:i + 1])[0]
+                         for i, o_ in enumerate(outs)]
+                batch_seq = torch.nn.utils.rnn.pad_sequence(fused, batch_first=True)
         mask = torch.ones(batch_seq.shape[0], batch_seq.shape[1], dtype=batch_seq.dtype, device=batch_seq.device)
         return batch_seq, mask

@@ -186,6 +186,20 @@ def adapter(x: Tensor, p: SD) -> Tensor:
     return x + linear(torch.relu(linear(x, p["0.weight"], p["0.bias"])), p["2.weight"], p["2.bias"])
 
 
+def gate_feature_fusion(sd: SD, seq: Tensor, q_raw: Tensor, c_raw: Tensor) -> Tensor:
+    """Learnable part of the quality-gate / conditioning path (ref models/audio_encoder.py:115-132 with
+    quality_gates.py:439-444,554 and audio_conditioning.py:455-460,578): project the raw 8 + 12 features, broadcast
+    over frames, concatenate and apply combined_fusion (Linear + ReLU; dropout is the identity).
+    seq [B,S,H], q_raw [B,8], c_raw [B,12]."""
+    qf = linear(torch.relu(linear(q_raw, sd["quality_gates.quality_projection.0.weight"], sd["quality_gates.quality_projection.0.bias"])),
+                sd["quality_gates.quality_projection.3.weight"], sd["quality_gates.quality_projection.3.bias"])
+    cf = linear(torch.relu(linear(c_raw, sd["audio_conditioning.conditioning_projection.0.weight"],
+                                  sd["audio_conditioning.conditioning_projection.0.bias"])),
+                sd["audio_conditioning.conditioning_projection.3.weight"], sd["audio_conditioning.conditioning_projection.3.bias"])
+    f = torch.cat([qf, cf], dim=-1)[:, None, :].expand(-1, seq.shape[1], -1)
+    return torch.relu(linear(torch.cat([seq, f], dim=-1), sd["combined_fusion.0.weight"], sd["combined_fusion.0.bias"]))
+
+
 def audio_encoder_forward(sd: SD, waves: Sequence[Tensor], cfg,
                           gate_features: Optional[Sequence[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """ref: models/audio_encoder.py:54-172 with quality gates / conditioning off

@@ -136,6 +136,28 @@ def main():
     save("audio_encoder.npz", cfg=json.dumps(A_CFG), adapter_dim=32, wave0=waves[0].numpy(), wave1=waves[1].numpy(),
          a_seq=a_seq.numpy(), a_mask=a_mask.numpy(), **sd_np(ae))
 
+    # ---------------- learnable gate-feature fusion (ref audio_encoder.py:25-52, :115-132) ----
+    # The DSP that produces the raw 8 quality + 12 conditioning features needs librosa/webrtcvad and cannot run
+    # here; the learnable layers behind it can: they are driven directly with synthetic raw features.
+    torch.manual_seed(13)
+    aeg = R["AudioEncoder"](model_name=da, adapter_dim=32, vad_method="librosa").eval()
+    seqg = torch.randn(2, 9, 128, requires_grad=True)
+    q_raw, c_raw = torch.rand(2, 8), torch.rand(2, 12)
+    outs = []
+    for i in range(2):
+        qf = aeg.quality_gates.quality_projection(q_raw[i][None])[0]
+        cf = aeg.audio_conditioning.conditioning_projection(c_raw[i][None])[0]
+        feats = torch.cat([qf, cf])[None].expand(9, -1)
+        outs.append(aeg.combined_fusion(torch.cat([seqg[i], feats], dim=-1)))
+    outg = torch.stack(outs)
+    gg = torch.randn_like(outg)
+    (outg * gg).sum().backward()
+    gsd = {"sd." + k: v.detach().numpy().copy() for k, v in aeg.state_dict().items() if not k.startswith("encoder.")}
+    ggr = {"grad." + k: p.grad.detach().numpy().copy() for k, p in aeg.named_parameters()
+           if p.grad is not None and not k.startswith("encoder.")}
+    save("gate_fusion.npz", seq=seqg.detach().numpy(), q_raw=q_raw.numpy(), c_raw=c_raw.numpy(), out=outg.detach().numpy(),
+         g_out=gg.numpy(), grad_seq=seqg.grad.numpy(), **gsd, **ggr)
+
     # ---------------- text encoder ------------------------------------------------------------
     te = R["TextEncoder"](model_name=dt, adapter_dim=32).eval()
     texts = ["w1 w2 w3 w4 w5 w6", "w10 w20 w30", "w7 w8 w9 w11 w12 w13 w14 w15 w16"]

@@ -210,3 +210,26 @@ def test_xattn_core_fast_and_generic_paths(M, Sq, Sk):
     _close(dq, qd.grad.float(), atol=5e-5, rtol=1e-3)
     _close(dk, kd.grad.float(), atol=5e-5, rtol=1e-3)
     _close(dv, vd.grad.float(), atol=5e-5, rtol=1e-3)
+
+
+def test_gate_feature_fusion_learnable_path(M):
+    """ref audio_encoder.py:115-132 driven with raw feature vectors (the DSP that produces them is out of scope):
+    forward and all gradients vs the golden vectors captured from the reference's own layers."""
+    from transformers import Wav2Vec2Config
+    from ser_amd.models import AudioEncoder
+    sd, gr, r = split_fixture(load_npz("gate_fusion.npz"))
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                        conv_dim=[64] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    ae = AudioEncoder(hf_config=wc, adapter_dim=32)           # gate flags on (the reference default)
+    missing, unexpected = ae.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") for k in missing)
+    ae = ae.cuda()
+    seq = t(r["seq"]).cuda().requires_grad_()
+    out = ae.fuse_gate_features(seq, t(r["q_raw"]).cuda(), t(r["c_raw"]).cuda())
+    _close(out, r["out"], **FWD)
+    out.backward(t(r["g_out"]).cuda())
+    _close(seq.grad, r["grad_seq"], **BWD)
+    named = dict(ae.named_parameters())
+    for k, gw in gr.items():
+        assert named[k].grad is not None, k
+        _close(named[k].grad, gw.numpy(), msg=k, **BWD)

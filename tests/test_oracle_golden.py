@@ -18,6 +18,18 @@ def test_audio_encoder():
     np.testing.assert_array_equal(mask.numpy(), r["a_mask"])
 
 
+def test_gate_feature_fusion_fwd_bwd():
+    sd, gr, r = split_fixture(load_npz("gate_fusion.npz"))
+    p = _leafs(sd)
+    seq = t(r["seq"]).requires_grad_()
+    out = O.gate_feature_fusion(p, seq, t(r["q_raw"]), t(r["c_raw"]))
+    np.testing.assert_allclose(out.detach().numpy(), r["out"], **TOL)
+    (out * t(r["g_out"])).sum().backward()
+    np.testing.assert_allclose(seq.grad.numpy(), r["grad_seq"], atol=1e-5, rtol=1e-4)
+    for k, g in gr.items():
+        np.testing.assert_allclose(p[k].grad.numpy(), g.numpy(), atol=1e-4, rtol=1e-3, err_msg=k)
+
+
 def test_text_encoder():
     z = load_npz("text_encoder.npz")
     sd, _, r = split_fixture(z)
