@@ -126,6 +126,8 @@ def main():
 
     from ser_amd.system import GradReducer, TrainStepper
     from ser_amd import _lib as L
+    if os.environ.get("SER_GEMM_LDS_PAD"):
+        L.lib.ser_debug_set_gemm_lds_pad(int(os.environ["SER_GEMM_LDS_PAD"]))
     if os.environ.get("SER_GEMM_PERSIST"):
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
     sysm, wc, xc = build_system(args.precision, dev, stress=args.stress)

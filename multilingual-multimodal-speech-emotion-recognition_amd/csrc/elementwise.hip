@@ -277,6 +277,146 @@ __global__ void conv0_finalize_kernel(const float2* __restrict__ partial, int ch
   cstats[(long long)b * C0 + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
 }
 
+// ------------------------------------------------------------------------------------------
+// Fast path for a compile-time (KW, ST): the GroupNorm statistics never touch the conv output.
+// With y_t = sum_j w_j x_{ST t + j}:   sum_t y_t = w . S,   sum_t y_t^2 = w^T R w,   where
+// S_j = sum_t x_{ST t + j} and R_jk = sum_t x_{ST t + j} x_{ST t + k} depend on the clip only
+// (KW + KW (KW+1)/2 numbers).  One workgroup per clip computes the clip statistics, S and R on
+// the normalised samples, then mean / rstd of every channel in double precision.
+// ------------------------------------------------------------------------------------------
+template <int KW, int ST>
+__global__ __launch_bounds__(512) void conv0_stats_kernel(const float* __restrict__ wave, int T, int L0,
+                                                           const float* __restrict__ w, int C0,
+                                                           float2* __restrict__ wstats, float2* __restrict__ cstats) {
+  constexpr int NR = KW * (KW + 1) / 2, NV = KW + NR;
+  __shared__ double red[8][NV];
+  __shared__ double tot[NV];
+  __shared__ double sh[2][8];
+  __shared__ float2 ws_sh;
+  const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const float* x = wave + (long long)b * T;
+  {
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < T; i += 512) {
+      const double v = x[i];
+      s += v;
+      q += v * v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) { sh[0][wv] = s; sh[1][wv] = q; }
+    __syncthreads();
+    if (tid == 0) {
+      double ss = 0.0, qq = 0.0;
+      for (int i = 0; i < 8; ++i) { ss += sh[0][i]; qq += sh[1][i]; }
+      const double mean = ss / T;
+      double var = qq / T - mean * mean;
+      if (var < 0.0) var = 0.0;
+      ws_sh = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-7)));
+      wstats[b] = ws_sh;
+    }
+    __syncthreads();
+  }
+  const float m = ws_sh.x, r = ws_sh.y;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  for (int t = tid; t < L0; t += 512) {
+    float xv[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) xv[j] = (x[t * ST + j] - m) * r;
+    int idx = KW;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      acc[j] += xv[j];
+#pragma unroll
+      for (int k = j; k < KW; ++k, ++idx) acc[idx] = fmaf(xv[j], xv[k], acc[idx]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double d = acc[i];
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane == 0) red[wv][i] = d;
+  }
+  __syncthreads();
+  if (tid < NV) {
+    double d = 0.0;
+    for (int i = 0; i < 8; ++i) d += red[i][tid];
+    tot[tid] = d;
+  }
+  __syncthreads();
+  for (int c = tid; c < C0; c += 512) {
+    double wj[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) wj[j] = w[c * KW + j];
+    double s = 0.0, q = 0.0;
+    int idx = KW;
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+      s += wj[j] * tot[j];
+#pragma unroll
+      for (int k = j; k < KW; ++k, ++idx) q += (k == j ? 1.0 : 2.0) * wj[j] * wj[k] * tot[idx];
+    }
+    const double mean = s / L0;
+    double var = q / L0 - mean * mean;
+    if (var < 0.0) var = 0.0;
+    cstats[(long long)b * C0 + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+  }
+}
+
+typedef float ser_v2f __attribute__((ext_vector_type(2)));
+
+// conv (KW packed FMAs per channel pair) + GroupNorm affine + erf-GELU + bf16 planes, channels-last.
+// One thread owns a channel pair over the workgroup's frames; the samples of a frame are a
+// wave-uniform LDS read; every store instruction of a wave covers 256 contiguous bytes and the
+// four waves of a workgroup complete a 1 KB row.
+template <int KW, int ST, bool LO>
+__global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restrict__ wave, const float2* __restrict__ wstats,
+                                                          const float* __restrict__ w, int T, int L0, int C0,
+                                                          const float2* __restrict__ cstats, const float* __restrict__ gn_g,
+                                                          const float* __restrict__ gn_b, bf16_t* __restrict__ yhi,
+                                                          bf16_t* __restrict__ ylo) {
+  __shared__ float xs[C0_FT * ST + KW];
+  const int b = blockIdx.y, t0 = blockIdx.x * C0_FT;
+  const int nt = min(C0_FT, L0 - t0);
+  const int nsamp = (nt - 1) * ST + KW;
+  const float2 ws = wstats[b];
+  const float* x = wave + (long long)b * T + (long long)t0 * ST;
+  for (int i = threadIdx.x; i < nsamp; i += 256) xs[i] = (x[i] - ws.x) * ws.y;
+  __syncthreads();
+  for (int cp = threadIdx.x; cp < C0 / 2; cp += 256) {
+    const int c = cp * 2;
+    ser_v2f wv[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j) wv[j] = ser_v2f{w[c * KW + j], w[(c + 1) * KW + j]};
+    const float2 st0 = cstats[(long long)b * C0 + c], st1 = cstats[(long long)b * C0 + c + 1];
+    const ser_v2f g = {gn_g[c] * st0.y, gn_g[c + 1] * st1.y};
+    const ser_v2f o = {gn_b[c] - st0.x * g.x, gn_b[c + 1] - st1.x * g.y};
+    uint32_t* ph = (uint32_t*)(yhi + ((long long)b * L0 + t0) * C0 + c);
+    uint32_t* pl = LO ? (uint32_t*)(ylo + ((long long)b * L0 + t0) * C0 + c) : nullptr;
+    const int rowu = C0 / 2;
+#pragma unroll 4
+    for (int t = 0; t < nt; ++t) {
+      ser_v2f acc = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < KW; ++j) acc = wv[j] * xs[t * ST + j] + acc;
+      acc = acc * g + o;
+      const float v0 = gelu_erf(acc.x), v1 = gelu_erf(acc.y);
+      if (LO) {
+        uint32_t h, l;
+        split_bf16x2(v0, v1, h, l);
+        ph[(long long)t * rowu] = h;
+        pl[(long long)t * rowu] = l;
+      } else {
+        ph[(long long)t * rowu] = pack_bf16x2(v0, v1);
+      }
+    }
+  }
+}
+
 size_t ser_conv0_scratch_bytes(int B, int L0, int C0) {
   const int chunks = ceil_div(L0, C0_FT);
   return (size_t)B * chunks * C0 * sizeof(float2) + (size_t)B * C0 * sizeof(float2) + (size_t)B * sizeof(float2) + 1024;
@@ -291,6 +431,17 @@ int ser_launch_conv0(const float* wave, int B, int T, const float* w, const floa
   float2* wstats = (float2*)p; p += (((size_t)B * sizeof(float2)) + 255) & ~(size_t)255;
   float2* partial = (float2*)p; p += (size_t)B * chunks * C0 * sizeof(float2);
   float2* cstats = (float2*)p;
+  if (KW == 10 && ST == 5) {
+    hipLaunchKernelGGL((conv0_stats_kernel<10, 5>), dim3(B), dim3(512), 0, st, wave, T, L0, w, C0, wstats, cstats);
+    if (ylo)
+      hipLaunchKernelGGL((conv0_apply_kernel<10, 5, true>), dim3(chunks, B), dim3(256), 0, st, wave, wstats, w, T, L0, C0,
+                         cstats, gn_g, gn_b, yhi, ylo);
+    else
+      hipLaunchKernelGGL((conv0_apply_kernel<10, 5, false>), dim3(chunks, B), dim3(256), 0, st, wave, wstats, w, T, L0, C0,
+                         cstats, gn_g, gn_b, yhi, ylo);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
   hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(1024), 0, st, wave, T, wstats);
   hipLaunchKernelGGL(conv0_kernel<false>, dim3(chunks, B), dim3(256), 0, st, wave, wstats, w, T, L0, C0, KW, ST, partial,
                      (const float2*)nullptr, gn_g, gn_b, (bf16_t*)nullptr, (bf16_t*)nullptr);

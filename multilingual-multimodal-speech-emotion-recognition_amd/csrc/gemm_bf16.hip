@@ -254,6 +254,9 @@ struct ProfRec {
 };
 static int g_gemm_persist_cap = 0;   // 0 = one workgroup per tile; N = persistent grid of at most N workgroups
 extern "C" int ser_debug_set_gemm_persist(int cap) { g_gemm_persist_cap = cap; return 0; }
+// experiment knob: extra dynamic LDS per workgroup, i.e. fewer resident GEMM workgroups per CU
+static int g_gemm_lds_pad = 0;
+extern "C" int ser_debug_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes; return 0; }
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
@@ -271,9 +274,9 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
   if (g.a_lo && g.w_lo)
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, 0, st, g, tiles, total);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
   else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, 0, st, g, tiles, total);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventRecord(rec.e1, st));
     g_prof.push_back(rec);

@@ -82,3 +82,23 @@ def test_xlmr_forward_golden(eng, prec, tol):
     assert (got - want)[valid].abs().max().item() < tol
     full = O.adapter(got, O.sub(sd, "adapter."))
     assert (full - t(r["t_seq"]))[valid].abs().max().item() < tol * 2
+
+
+def test_wav2vec2_generic_conv0_geometry(eng):
+    """A first conv layer that is not (kernel 10, stride 5) takes the generic conv0 kernels; DC offset and a
+    different clip length exercise the clip normalisation and the ragged last chunk."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    E, L = eng
+    torch.manual_seed(3)
+    for kernel, stride in (([8, 3, 2], [4, 2, 2]), ([10, 3, 2], [5, 2, 2])):
+        wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=128,
+                            conv_dim=[64] * 3, conv_kernel=kernel, conv_stride=stride, num_conv_pos_embeddings=16,
+                            num_conv_pos_embedding_groups=4)
+        sd = {k: v.detach() for k, v in Wav2Vec2Model(wc).state_dict().items()}
+        cfg = O.wav2vec2_config(hidden=128, layers=1, heads=2, ffn=128, conv_dim=wc.conv_dim, conv_kernel=kernel,
+                                conv_stride=stride, pos_kernel=16, pos_groups=4, eps=wc.layer_norm_eps)
+        e = E.Wav2Vec2Engine(wc, sd, "cuda", L.PREC_BF16X3)
+        waves = 0.1 * torch.randn(3, 3001) + 0.3
+        got = e.forward(waves.cuda()).cpu()
+        want = O.wav2vec2_forward(sd, torch.stack([O.normalise_waveform(w) for w in waves]), cfg)
+        assert (got - want).abs().max().item() < 2e-4, (kernel, stride)
