@@ -187,6 +187,25 @@ int ser_linear_wgrad_batch(const void* const* ptrs, const int* dims, int nprob, 
 int ser_linear_fwd_ln2(const float* x, const float* W, const float* bias, int act, const float* g1, const float* b1,
                        const float* g2, const float* b2, float eps, float* y1, float* y2, float* stats, float* y,
                        int M, int N, int K, void* stream);
+/* The residual stack of the deep classifier in ONE launch per direction (classifier.py:77-89 DeepResidualBlock,
+ * :209-216 the 35-block loop), for M <= 16 rows and D <= 512 (a multiple of 16):
+ *   x1 = LN(h; g1,b1)   u = LN(x1; g2,b2)   a = relu(u W1^T + c1)   h' = x1 + a W2^T + c2.
+ * D/16 resident workgroups own 16 output columns each and hand the M x D activations to each other through
+ * device memory (coherent loads / stores + one epoch word per workgroup, bounded waits).
+ * ptr_table  : device array [L][8] of parameter pointers {g1,b1,g2,b2,W1,c1,W2,c2} per block
+ * grad_table : device array [L][4] of gradient pointers {dg1,db1,dg2,db2} per block
+ * flags      : >= 65 device words of scratch per launch (zeroed by the call)
+ * Hs[L][M][D] block outputs, X1/U/A[L][M][D] and ST[L][4][M] saved for backward.
+ * ser_stack_bwd: DH[L+1][M][D], DH[L] = gradient at the stack output on entry; on return DH[i] = gradient at the input
+ * of block i; DA/DU/DX1[L][M][D] feed ser_linear_wgrad_batch and ser_stack_ln_param_bwd. */
+int ser_stack_supported(int L, int M, int D);
+int ser_stack_fwd(const void* ptr_table, const float* x0, float* Hs, float* X1, float* U, float* A, float* ST, int L,
+                  int M, int D, float eps, void* flags, void* stream);
+int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const float* X1, const float* A,
+                  const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* flags,
+                  void* stream);
+int ser_stack_ln_param_bwd(const void* grad_table, const float* x0, const float* Hs, const float* X1, const float* ST,
+                           const float* DU, const float* DX1, int L, int M, int D, int accumulate, void* stream);
 /* relu_mask (may be NULL): the ReLU OUTPUT of the layer that produced x; when given, dx is multiplied by
  * relu'(mask), i.e. the activation backward is fused into the dgrad epilogue. */
 int ser_linear_dgrad(const float* dy, const float* W, const float* relu_mask, float* dx, int M, int N, int K,

@@ -179,6 +179,40 @@ def linear_fwd_ln2(x, W, b, act, g1, b1, g2, b2, eps=1e-5):
     return y, y1, y2, stats
 
 
+# ---- persistent walk of the classifier's residual stack (csrc/persist.hip) ---------------------------------------------
+USE_STACK = True     # one launch per direction for the whole stack when the shape allows it (M <= 16, D <= 512)
+
+
+def stack_supported(L_, M, D):
+    return USE_STACK and bool(L.lib.ser_stack_supported(L_, M, D))
+
+
+def stack_fwd(x0, table, L_, flags, eps=1e-5):
+    """All L residual blocks forward -> (Hs[L,M,D] block outputs, X1, U, A [L,M,D], ST[L,4,M])."""
+    M, D = x0.shape
+    Hs, X1, U, A = (empty(L_, M, D, like=x0) for _ in range(4))
+    ST = empty(L_, 4, M, like=x0)
+    L.check(L.lib.ser_stack_fwd(L.ptr(table), L.ptr(x0), L.ptr(Hs), L.ptr(X1), L.ptr(U), L.ptr(A), L.ptr(ST), L_, M, D, eps,
+                                L.ptr(flags), L.stream_ptr()), "ser_stack_fwd")
+    return Hs, X1, U, A, ST
+
+
+def stack_bwd(table, x0, Hs, X1, A, ST, DH, flags):
+    """Backward dgrad chain of the stack.  DH[L] holds the gradient at the stack output on entry; on return DH[i] is
+    the gradient at the input of block i (DH[0]: at x0).  -> DA, DU, DX1 [L,M,D] for the batched parameter gradients."""
+    L_, M, D = Hs.shape
+    DA, DU, DX1 = (empty(L_, M, D, like=x0) for _ in range(3))
+    L.check(L.lib.ser_stack_bwd(L.ptr(table), L.ptr(x0), L.ptr(Hs), L.ptr(X1), L.ptr(A), L.ptr(ST), L.ptr(DH), L.ptr(DA),
+                                L.ptr(DU), L.ptr(DX1), L_, M, D, L.ptr(flags), L.stream_ptr()), "ser_stack_bwd")
+    return DA, DU, DX1
+
+
+def stack_ln_param_bwd(gtable, x0, Hs, X1, ST, DU, DX1, accumulate=False):
+    L_, M, D = Hs.shape
+    L.check(L.lib.ser_stack_ln_param_bwd(L.ptr(gtable), L.ptr(x0), L.ptr(Hs), L.ptr(X1), L.ptr(ST), L.ptr(DU), L.ptr(DX1),
+                                         L_, M, D, 1 if accumulate else 0, L.stream_ptr()), "ser_stack_ln_param_bwd")
+
+
 def ln2_bwd(du, dres, x, y1, stats, g1, g2, dg1, db1, dg2, db2, accumulate=False):
     """dx = LN1'(LN2'(du) + dres) and the four parameter gradients in one launch."""
     rows, D = du.shape

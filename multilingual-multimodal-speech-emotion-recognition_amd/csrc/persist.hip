@@ -106,6 +106,390 @@ __global__ __launch_bounds__(512) void barrier_probe_kernel(GridBar gb, float* d
   if (bad) atomicAdd(errors, bad);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The residual stack of the deep classifier (ref classifier.py:77-89 DeepResidualBlock, :209-216 the loop):
+//   x1 = LN(h; g1,b1)   u = LN(x1; g2,b2)   a = relu(u W1^T + c1)   h' = x1 + a W2^T + c2
+// at M <= 16 rows.  One launch walks all L blocks: workgroup b owns output columns [16 b, 16 b + 16) of every
+// Linear (its weight slice is fetched into registers before the hand-off wait), the M x D activations are exchanged
+// through device memory with the coherent accesses above, two hand-offs per block.  Arithmetic and summation order
+// are those of skinny_fwd_ln2_kernel / skinny_fwd_kernel (gemm_f32.hip), so results are bit-identical to the
+// one-launch-per-Linear path.
+// ------------------------------------------------------------------------------------------
+struct StackBlockPtrs {
+  const float *g1, *b1, *g2, *b2, *W1, *c1, *W2, *c2;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+SER_DEVFN float4 ld_coh4(const float* p) {
+  const float2 lo = ld_coh2(p), hi = ld_coh2(p + 2);
+  return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+
+constexpr int SW = 8;   // waves per workgroup
+
+__global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs* __restrict__ tab, const float* __restrict__ x0,
+                                                            float* Hs, float* __restrict__ X1, float* __restrict__ U,
+                                                            float* A, float* __restrict__ ST, int L, int M, int D, float eps,
+                                                            GridBar gb) {
+  __shared__ float red[SW][64][4];
+  __shared__ float st[16][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int n0 = blockIdx.x * 16, n = n0 + i;
+  const int nch4 = D >> 2, nchunk = D >> 4;
+  const int nit = (nchunk - w + SW - 1) / SW;          // <= 4 (D <= 512)
+  const long long MD = (long long)M * D;
+  const int ri = min(i, M - 1);
+  unsigned epoch = 0;
+  float4 b[4];
+  {
+    const float* wr = tab[0].W1 + (long long)n * D + q * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = *(const float4*)(wr + min(w + u * SW, nchunk - 1) * 16);
+  }
+  for (int blk = 0; blk < L; ++blk) {
+    const StackBlockPtrs P = tab[blk];
+    const float* h = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
+    // ---- statistics of both LayerNorms, one wave per row (rows w, w + 8)
+    for (int row = w; row < 16; row += SW) {
+      const int rr = min(row, M - 1);
+      float4 v[2];
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = lane + 64 * e;
+        v[e] = c < nch4 ? ld_coh4(h + (long long)rr * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const float* gp = pass == 0 ? P.g1 : P.g2;
+        const float* bp = pass == 0 ? P.b1 : P.b2;
+        const float mean = wave_sum(s) / (float)D;
+        float qq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          if (lane + 64 * e < nch4) {
+            const float a = v[e].x - mean, bb = v[e].y - mean, c2 = v[e].z - mean, d = v[e].w - mean;
+            qq += (a * a + bb * bb) + (c2 * c2 + d * d);
+          }
+        const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)D + eps);
+        if (lane == 0) { st[row][2 * pass] = mean; st[row][2 * pass + 1] = rstd; }
+        s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = lane + 64 * e;
+          if (c < nch4) {
+            const float4 gm = *(const float4*)(gp + c * 4), bt = *(const float4*)(bp + c * 4);
+            float4 o;
+            o.x = (v[e].x - mean) * rstd * gm.x + bt.x; o.y = (v[e].y - mean) * rstd * gm.y + bt.y;
+            o.z = (v[e].z - mean) * rstd * gm.z + bt.z; o.w = (v[e].w - mean) * rstd * gm.w + bt.w;
+            if (blockIdx.x == 0 && row < M)
+              *(float4*)((pass == 0 ? X1 : U) + blk * MD + (long long)row * D + c * 4) = o;
+            v[e] = o;
+            s += (o.x + o.y) + (o.z + o.w);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+      const int row = threadIdx.x >> 2, which = threadIdx.x & 3;
+      if (row < M) ST[(long long)blk * 4 * M + which * M + row] = st[row][which];
+    }
+    // ---- a = relu(u W1^T + c1)
+    {
+      const float m1 = st[i][0], r1 = st[i][1], m2 = st[i][2], r2 = st[i][3];
+      const float* xr = h + (long long)ri * D + q * 4;
+      float4 a[4], G1[4], B1[4], G2[4], B2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = min(w + u * SW, nchunk - 1);
+        const int ko = c * 16 + q * 4;
+        a[u] = ld_coh4(xr + c * 16);
+        G1[u] = *(const float4*)(P.g1 + ko); B1[u] = *(const float4*)(P.b1 + ko);
+        G2[u] = *(const float4*)(P.g2 + ko); B2[u] = *(const float4*)(P.b2 + ko);
+      }
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float4 t;
+        t.x = (((a[u].x - m1) * r1 * G1[u].x + B1[u].x) - m2) * r2 * G2[u].x + B2[u].x;
+        t.y = (((a[u].y - m1) * r1 * G1[u].y + B1[u].y) - m2) * r2 * G2[u].y + B2[u].y;
+        t.z = (((a[u].z - m1) * r1 * G1[u].z + B1[u].z) - m2) * r2 * G2[u].z + B2[u].z;
+        t.w = (((a[u].w - m1) * r1 * G1[u].w + B1[u].w) - m2) * r2 * G2[u].w + B2[u].w;
+        if (u >= nit) t = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.w, b[u].w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+    // weight slice of the second Linear: in flight during the reduction and the hand-off
+    {
+      const float* wr = P.W2 + (long long)n * D + q * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *(const float4*)(wr + min(w + u * SW, nchunk - 1) * 16);
+    }
+    __syncthreads();
+    float x1v[4] = {0.f, 0.f, 0.f, 0.f};                 // residual operand of this thread's outputs (wave 0)
+    if (w == 0) {
+      const float bv = P.c1[n], g1n = P.g1[n], b1n = P.b1[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
+        v = fmaxf(v + bv, 0.f);
+        st_coh(A + blk * MD + (long long)m * D + n, v);
+        const float hv = ld_coh(h + (long long)m * D + n);
+        x1v[r] = (hv - st[m][0]) * st[m][1] * g1n + b1n;
+      }
+    }
+    if (!grid_arrive_wait(gb, ++epoch)) return;
+    // ---- h' = x1 + a W2^T + c2
+    {
+      const float* ar = A + blk * MD + (long long)ri * D + q * 4;
+      float4 a[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = ld_coh4(ar + min(w + u * SW, nchunk - 1) * 16);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u >= nit) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+    if (blk + 1 < L) {
+      const float* wr = tab[blk + 1].W1 + (long long)n * D + q * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *(const float4*)(wr + min(w + u * SW, nchunk - 1) * 16);
+    }
+    __syncthreads();
+    if (w == 0) {
+      const float bv = P.c2[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
+        v = v + bv;
+        v += x1v[r];
+        st_coh(Hs + blk * MD + (long long)m * D + n, v);
+      }
+    }
+    if (!grid_arrive_wait(gb, ++epoch)) return;
+  }
+}
+
+// Backward of the same stack.  Per block (last first), with dh' the gradient at the block output:
+//   da = (dh' W2) * relu'(a)      du = da W1      dx1 = dh' + LN2'(du)      dh = LN1'(dx1)
+// Workgroup b owns columns [16 b, 16 b + 16) of da and du (the reduction over the rows of W is split over the waves,
+// as in skinny_dgrad16_kernel); dh' lives in an LDS panel that every workgroup recomputes from du (row-wise
+// LayerNorm backward, one wave per row, as ln2_bwd_kernel).  Two hand-offs per block.  dh', da, du and dx1 of
+// every block are kept for the batched weight / LayerNorm-parameter gradients issued after this kernel.
+__global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs* __restrict__ tab, const float* __restrict__ x0,
+                                                            const float* __restrict__ Hs, const float* __restrict__ X1,
+                                                            const float* __restrict__ A, const float* __restrict__ ST,
+                                                            float* __restrict__ DH, float* DA, float* DU,
+                                                            float* __restrict__ DX1, int L, int M, int D, GridBar gb) {
+  extern __shared__ float panel[];                   // [16][D]  gradient at the current block's output
+  __shared__ float red[SW][64][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int c = blockIdx.x * 16 + i;                  // output column of this lane
+  const int nch4 = D >> 2;
+  const int nsteps = D >> 2;                          // reduction steps of 4 rows of W
+  const int nit = (nsteps - w + SW - 1) / SW;         // <= 16
+  const long long MD = (long long)M * D;
+  const int ri = min(i, M - 1);
+  unsigned epoch = 0;
+  for (int idx = threadIdx.x; idx < M * nch4; idx += SW * 64)
+    ((float4*)panel)[idx] = ((const float4*)(DH + (long long)L * MD))[idx];
+  float bw[16];
+  {
+    const float* Wp = tab[L - 1].W2;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bw[u] = Wp[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
+  }
+  __syncthreads();
+  for (int blk = L - 1; blk >= 0; --blk) {
+    const StackBlockPtrs P = tab[blk];
+    // ---- da = (dh' W2) * relu'(a)
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int nn = (w + u * SW) * 4 + q;
+        const float av = (u < nit && nn < D) ? panel[ri * D + min(nn, D - 1)] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) bw[u] = P.W1[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
+        v = A[blk * MD + (long long)m * D + c] > 0.f ? v : 0.f;
+        st_coh(DA + blk * MD + (long long)m * D + c, v);
+      }
+    }
+    if (!grid_arrive_wait(gb, ++epoch)) return;
+    // ---- du = da W1
+    {
+      const float* dar = DA + blk * MD + (long long)ri * D;
+      float av[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) av[u] = ld_coh(dar + min((w + u * SW) * 4 + q, D - 1));
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int nn = (w + u * SW) * 4 + q;
+        const float a1 = (u < nit && nn < D) ? av[u] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+    if (blk > 0) {
+      const float* Wp = tab[blk - 1].W2;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) bw[u] = Wp[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
+        st_coh(DU + blk * MD + (long long)m * D + c, v);
+      }
+    }
+    if (!grid_arrive_wait(gb, ++epoch)) return;
+    // ---- panel <- LN1'(panel + LN2'(du)), rows w, w + 8
+    {
+      const float* hin = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
+      const float* stp = ST + (long long)blk * 4 * M;
+      for (int row = w; row < M; row += SW) {
+        const float m1 = stp[row], r1 = stp[M + row], m2 = stp[2 * M + row], r2 = stp[3 * M + row];
+        float4 xh[2], dgv[2], d1[2];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ch = lane + 64 * e;
+          if (ch < nch4) {
+            const float4 zz = *(const float4*)(X1 + blk * MD + (long long)row * D + ch * 4);
+            const float4 d = ld_coh4(DU + blk * MD + (long long)row * D + ch * 4);
+            const float4 gm = *(const float4*)(P.g2 + ch * 4);
+            xh[e] = make_float4((zz.x - m2) * r2, (zz.y - m2) * r2, (zz.z - m2) * r2, (zz.w - m2) * r2);
+            dgv[e] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
+            s1 += (dgv[e].x + dgv[e].y) + (dgv[e].z + dgv[e].w);
+            s2 += (dgv[e].x * xh[e].x + dgv[e].y * xh[e].y) + (dgv[e].z * xh[e].z + dgv[e].w * xh[e].w);
+          }
+        }
+        float a1 = wave_sum(s1) / (float)D, a2 = wave_sum(s2) / (float)D;
+        s1 = 0.f; s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ch = lane + 64 * e;
+          if (ch < nch4) {
+            d1[e].x = r2 * (dgv[e].x - a1 - xh[e].x * a2);
+            d1[e].y = r2 * (dgv[e].y - a1 - xh[e].y * a2);
+            d1[e].z = r2 * (dgv[e].z - a1 - xh[e].z * a2);
+            d1[e].w = r2 * (dgv[e].w - a1 - xh[e].w * a2);
+            const float4 ee = *(const float4*)(panel + row * D + ch * 4);
+            d1[e].x += ee.x; d1[e].y += ee.y; d1[e].z += ee.z; d1[e].w += ee.w;
+            if (blockIdx.x == 0) *(float4*)(DX1 + blk * MD + (long long)row * D + ch * 4) = d1[e];
+            const float4 zz = *(const float4*)(hin + (long long)row * D + ch * 4);
+            const float4 gm = *(const float4*)(P.g1 + ch * 4);
+            xh[e] = make_float4((zz.x - m1) * r1, (zz.y - m1) * r1, (zz.z - m1) * r1, (zz.w - m1) * r1);
+            dgv[e] = make_float4(d1[e].x * gm.x, d1[e].y * gm.y, d1[e].z * gm.z, d1[e].w * gm.w);
+            s1 += (dgv[e].x + dgv[e].y) + (dgv[e].z + dgv[e].w);
+            s2 += (dgv[e].x * xh[e].x + dgv[e].y * xh[e].y) + (dgv[e].z * xh[e].z + dgv[e].w * xh[e].w);
+          }
+        }
+        a1 = wave_sum(s1) / (float)D; a2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int ch = lane + 64 * e;
+          if (ch < nch4) {
+            float4 o;
+            o.x = r1 * (dgv[e].x - a1 - xh[e].x * a2);
+            o.y = r1 * (dgv[e].y - a1 - xh[e].y * a2);
+            o.z = r1 * (dgv[e].z - a1 - xh[e].z * a2);
+            o.w = r1 * (dgv[e].w - a1 - xh[e].w * a2);
+            *(float4*)(panel + row * D + ch * 4) = o;
+            if (blockIdx.x == 0) *(float4*)(DH + blk * MD + (long long)row * D + ch * 4) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// LayerNorm-parameter gradients of all blocks in one launch (off the dgrad chain):
+//   dg2 = sum_m du * xhat2   db2 = sum_m du   dg1 = sum_m dx1 * xhat1   db1 = sum_m dx1
+// grid (D / 64, L); rows are added in the order of ln2_bwd_kernel (wave w owned rows w, w + 8; waves in order).
+struct StackGradPtrs {
+  float *dg1, *db1, *dg2, *db2;
+};
+__global__ __launch_bounds__(64) void stack_ln_param_kernel(const StackGradPtrs* __restrict__ gtab, const float* __restrict__ x0,
+                                                            const float* __restrict__ Hs, const float* __restrict__ X1,
+                                                            const float* __restrict__ ST, const float* __restrict__ DU,
+                                                            const float* __restrict__ DX1, int L, int M, int D,
+                                                            int accumulate) {
+  const int col = blockIdx.x * 64 + threadIdx.x, blk = blockIdx.y;
+  if (col >= D) return;
+  const long long MD = (long long)M * D;
+  const float* hin = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
+  const float* stp = ST + (long long)blk * 4 * M;
+  float tg1 = 0.f, tb1 = 0.f, tg2 = 0.f, tb2 = 0.f;
+  for (int ww = 0; ww < SW; ++ww) {
+    float ag1 = 0.f, ab1 = 0.f, ag2 = 0.f, ab2 = 0.f;
+    for (int row = ww; row < M; row += SW) {
+      const float m1 = stp[row], r1 = stp[M + row], m2 = stp[2 * M + row], r2 = stp[3 * M + row];
+      const float d = DU[blk * MD + (long long)row * D + col];
+      const float xh2 = (X1[blk * MD + (long long)row * D + col] - m2) * r2;
+      ag2 += d * xh2;
+      ab2 += d;
+      const float d1 = DX1[blk * MD + (long long)row * D + col];
+      const float xh1 = (hin[(long long)row * D + col] - m1) * r1;
+      ag1 += d1 * xh1;
+      ab1 += d1;
+    }
+    if (ww == 0) { tg1 = ag1; tb1 = ab1; tg2 = ag2; tb2 = ab2; }
+    else { tg1 += ag1; tb1 += ab1; tg2 += ag2; tb2 += ab2; }
+  }
+  const StackGradPtrs G = gtab[blk];
+  if (accumulate) { tg1 += G.dg1[col]; tb1 += G.db1[col]; tg2 += G.dg2[col]; tb2 += G.db2[col]; }
+  G.dg1[col] = tg1; G.db1[col] = tb1; G.dg2[col] = tg2; G.db2[col] = tb2;
+}
+
 }  // namespace
 
 extern "C" int ser_debug_barrier_probe(int G, int rounds, int mode, void* flags, void* data, void* errors, void* stream) {
@@ -114,6 +498,57 @@ extern "C" int ser_debug_barrier_probe(int G, int rounds, int mode, void* flags,
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(flags, 0, 65 * sizeof(unsigned), st) != hipSuccess) return SER_E_HIP;
   hipLaunchKernelGGL(barrier_probe_kernel, dim3(G), dim3(512), 0, st, gb, (float*)data, rounds, mode, (unsigned*)errors);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+static int stack_check(int L, int M, int D) {
+  SER_REQUIRE(L >= 1 && M >= 1 && M <= 16 && D >= 16 && D <= 512 && D % 16 == 0,
+              "classifier stack: L=%d M=%d D=%d unsupported (M <= 16, D a multiple of 16 up to 512)", L, M, D);
+  return SER_OK;
+}
+
+extern "C" int ser_stack_supported(int L, int M, int D) {
+  return (L >= 1 && M >= 1 && M <= 16 && D >= 16 && D <= 512 && D % 16 == 0) ? 1 : 0;
+}
+
+extern "C" int ser_stack_fwd(const void* ptr_table, const float* x0, float* Hs, float* X1, float* U, float* A, float* ST,
+                             int L, int M, int D, float eps, void* flags, void* stream) {
+  SER_TRY(stack_check(L, M, D));
+  hipStream_t st = (hipStream_t)stream;
+  GridBar gb{(unsigned*)flags, (unsigned*)flags + 64, D / 16};
+  if (hipMemsetAsync(flags, 0, 65 * sizeof(unsigned), st) != hipSuccess) {
+    ser_set_error("classifier stack: memset failed");
+    return SER_E_HIP;
+  }
+  hipLaunchKernelGGL(stack_fwd_kernel, dim3(D / 16), dim3(SW * 64), 0, st, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, U, A,
+                     ST, L, M, D, eps, gb);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const float* X1, const float* A,
+                             const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* flags,
+                             void* stream) {
+  SER_TRY(stack_check(L, M, D));
+  hipStream_t st = (hipStream_t)stream;
+  GridBar gb{(unsigned*)flags, (unsigned*)flags + 64, D / 16};
+  if (hipMemsetAsync(flags, 0, 65 * sizeof(unsigned), st) != hipSuccess) {
+    ser_set_error("classifier stack: memset failed");
+    return SER_E_HIP;
+  }
+  hipLaunchKernelGGL(stack_bwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)16 * D * sizeof(float), st,
+                     (const StackBlockPtrs*)ptr_table, x0, Hs, X1, A, ST, DH, DA, DU, DX1, L, M, D, gb);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_stack_ln_param_bwd(const void* grad_table, const float* x0, const float* Hs, const float* X1,
+                                      const float* ST, const float* DU, const float* DX1, int L, int M, int D, int accumulate,
+                                      void* stream) {
+  SER_TRY(stack_check(L, M, D));
+  hipLaunchKernelGGL(stack_ln_param_kernel, dim3((D + 63) / 64, L), dim3(64), 0, (hipStream_t)stream,
+                     (const StackGradPtrs*)grad_table, x0, Hs, X1, ST, DU, DX1, L, M, D, accumulate);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

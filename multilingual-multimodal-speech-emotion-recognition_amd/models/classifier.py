@@ -74,8 +74,16 @@ class _ClassifierFn(torch.autograd.Function):
         h = O.act_fwd(y0, O.ACT_RELU)
         h0 = h
         blocks = []
+        stack = None
+        nblk = len(dc.residual_layers)
+        if nblk and O.stack_supported(nblk, h.shape[0], h.shape[1]):
+            # the whole residual stack in one persistent launch
+            tab, _, flags = m._stack_tables()
+            Hs, X1, U, A, ST = O.stack_fwd(h, tab, nblk, flags[0], dc.layer_norms[0].eps)
+            stack = (Hs, X1, U, A, ST)
+            h = Hs[nblk - 1]
         fused_ln = h.shape[1] <= 512
-        for blk, lno in zip(dc.residual_layers, dc.layer_norms):
+        for blk, lno in (() if stack is not None else zip(dc.residual_layers, dc.layer_norms)):
             b = blk.block
             hin = h
             if fused_ln and hin.shape[0] <= 16 and hin.shape[1] % 16 == 0:
@@ -101,7 +109,7 @@ class _ClassifierFn(torch.autograd.Function):
         uh = O.linear_fwd(f, uh_[0].weight, uh_[0].bias, O.ACT_RELU)
         unc = O.linear_fwd(uh, uh_[3].weight, uh_[3].bias, O.ACT_SIGMOID)
         ctx.m = m
-        ctx.saved = (x, ln0, h0, blocks, h, lnF, f, uh, unc)
+        ctx.saved = (x, ln0, h0, blocks, h, lnF, f, uh, unc, stack)
         ctx.need_dx = x.requires_grad
         ctx.mark_non_differentiable(f)
         return logits, unc, f
@@ -111,7 +119,7 @@ class _ClassifierFn(torch.autograd.Function):
         m = ctx.m
         dc, uh_ = m.deep_classifier, m.uncertainty_head
         ip, op = dc.input_projection, dc.output_projection
-        x, ln0, h0, blocks, h_last, lnF, f, uh, unc = ctx.saved
+        x, ln0, h0, blocks, h_last, lnF, f, uh, unc, stack = ctx.saved
         fp = m._flat
         acc = fp.accumulating()
         g = fp.gview
@@ -135,10 +143,24 @@ class _ClassifierFn(torch.autograd.Function):
         O.act_bwd(df, f, O.ACT_RELU)
         dtf = O.ln_bwd(df, lnF, op[1].weight, g(op[1].weight), g(op[1].bias), acc)
         O.linear_wgrad(dtf, h_last, g(op[0].weight), g(op[0].bias), acc)
-        dh = O.linear_dgrad(dtf, op[0].weight)
+        wg = []
+        if stack is not None:
+            Hs, X1, U, A, ST = stack
+            nblk, Mr, Dd = Hs.shape
+            tab, gtab, flags = m._stack_tables()
+            DH = torch.empty(nblk + 1, Mr, Dd, dtype=torch.float32, device=dev)
+            O.linear_dgrad(dtf, op[0].weight, out=DH[nblk])
+            DA, DU, DX1 = O.stack_bwd(tab, h0, Hs, X1, A, ST, DH, flags[1])
+            O.stack_ln_param_bwd(gtab, h0, Hs, X1, ST, DU, DX1, acc)
+            for i in range(nblk - 1, -1, -1):
+                b = dc.residual_layers[i].block
+                wg.append((DH[i + 1], A[i], g(b[4].weight), g(b[4].bias)))
+                wg.append((DA[i], U[i], g(b[1].weight), g(b[1].bias)))
+            dh = DH[0]
+        else:
+            dh = O.linear_dgrad(dtf, op[0].weight)
         # residual stack, last block first.  The weight gradients are only collected here and issued in ONE batched
         # launch after the loop: they are off the dgrad chain, which is the critical path of this backward.
-        wg = []
         for i in range(len(blocks) - 1, -1, -1):
             lnA, lnB, u, a, hin, x1, stats = blocks[i]
             b, lno = dc.residual_layers[i].block, dc.layer_norms[i]
@@ -152,7 +174,8 @@ class _ClassifierFn(torch.autograd.Function):
             else:
                 dx1 = O.ln_bwd(du, lnB, b[0].weight, g(b[0].weight), g(b[0].bias), acc, dx_add=dh)
                 dh = O.ln_bwd(dx1, lnA, lno.weight, g(lno.weight), g(lno.bias), acc)
-        O.linear_wgrad_batch(wg, acc)
+        if wg:
+            O.linear_wgrad_batch(wg, acc)
         # input projection
         O.act_bwd(dh, h0, O.ACT_RELU)
         dt0 = O.ln_bwd(dh, ln0, ip[1].weight, g(ip[1].weight), g(ip[1].bias), acc)
@@ -190,6 +213,26 @@ class AdvancedOpenMaxClassifier(nn.Module):
     def _run(self, x):
         self._flat.ensure()
         return _ClassifierFn.apply(self, x, *self._flat.params)
+
+    def _stack_tables(self):
+        """Device tables of parameter / gradient pointers of the residual stack for the persistent kernels
+        (csrc/persist.hip: StackBlockPtrs, StackGradPtrs) + their hand-off flag words.  Rebuilt when the flat
+        buckets move (`.to(device)`, re-flattening)."""
+        fp, dc = self._flat, self.deep_classifier
+        key = (fp.flat.data_ptr(), fp.gflat.data_ptr())
+        if getattr(self, "_stack_cache", None) is None or self._stack_cache[0] != key:
+            rows, grows = [], []
+            for blk, lno in zip(dc.residual_layers, dc.layer_norms):
+                b = blk.block
+                ps = (lno.weight, lno.bias, b[0].weight, b[0].bias, b[1].weight, b[1].bias, b[4].weight, b[4].bias)
+                rows.append([p.data_ptr() for p in ps])
+                grows.append([fp.gview(p).data_ptr() for p in ps[:4]])
+            dev = fp.flat.device
+            tab = torch.tensor(rows, dtype=torch.int64).to(dev)
+            gtab = torch.tensor(grows, dtype=torch.int64).to(dev)
+            flags = torch.zeros(2, 128, dtype=torch.int32, device=dev)
+            self._stack_cache = (key, tab, gtab, flags)
+        return self._stack_cache[1:]
 
     def penultimate_features(self, x: torch.Tensor) -> torch.Tensor:
         """The 256-d features train.py:222-236 recomputes layer by layer for fit_weibull."""

@@ -233,3 +233,53 @@ def test_gate_feature_fusion_learnable_path(M):
     for k, gw in gr.items():
         assert named[k].grad is not None, k
         _close(named[k].grad, gw.numpy(), msg=k, **BWD)
+
+
+@pytest.mark.parametrize("rows,D,depth", [(16, 512, 35), (5, 512, 4), (16, 64, 3), (3, 128, 2), (1, 256, 1)])
+def test_classifier_persistent_stack_equals_per_block_launches(M, rows, D, depth):
+    """The one-launch walk of the residual stack (csrc/persist.hip) against the launch-per-Linear path: same
+    arithmetic in the same order forward, so the logits must agree bit for bit; backward the LayerNorm expressions
+    are contracted differently by the compiler, so gradients agree to a few ulps per block (checked at 1e-4 relative
+    after 35 blocks); a second backward must accumulate; the hand-off waits must never have been abandoned."""
+    from ser_amd import _ops as OP
+    from ser_amd.models.classifier import AdvancedOpenMaxClassifier
+    torch.manual_seed(rows * 1000 + D + depth)
+    m = AdvancedOpenMaxClassifier(input_dim=D, num_labels=4, num_layers=depth, base_dim=D).cuda().train()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    x = torch.randn(rows, D, device="cuda", requires_grad=True)
+    gl, gu = torch.randn(rows, 4, device="cuda"), torch.randn(rows, 1, device="cuda")
+
+    def run(flag, twice=False):
+        OP.USE_STACK = flag
+        try:
+            m.zero_grad(set_to_none=True)
+            x.grad = None
+            for _ in range(2 if twice else 1):
+                logits, unc, _ = m(x, use_openmax=False, return_uncertainty=True)
+                torch.autograd.backward([logits, unc], [gl, gu])
+            torch.cuda.synchronize()
+            return logits.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()
+                                                             if p.grad is not None}
+        finally:
+            OP.USE_STACK = True
+
+    assert OP.stack_supported(depth, rows, D)
+    a, b = run(True), run(False)
+    assert int(m._stack_cache[3][:, 64].abs().sum()) == 0, "a hand-off wait was abandoned"
+    if D == 512:      # same K split over the waves as the launch-per-Linear kernels
+        assert torch.equal(a[0], b[0]), f"logits differ by {(a[0] - b[0]).abs().max().item()}"
+    else:
+        np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    def same(u, v, what):
+        scale = float(v.abs().max()) + 1e-12
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=what)
+
+    same(a[1], b[1], "input gradient")
+    assert a[2].keys() == b[2].keys()
+    for k in a[2]:
+        same(a[2][k], b[2][k], k)
+    a2 = run(True, twice=True)
+    for k in a2[2]:
+        same(a2[2][k], 2 * a[2][k], "accumulated " + k)
