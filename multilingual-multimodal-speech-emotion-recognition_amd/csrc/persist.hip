@@ -152,17 +152,35 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
   for (int blk = 0; blk < L; ++blk) {
     const StackBlockPtrs P = tab[blk];
     const float* h = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
+    // every load that crosses workgroups is issued here, back to back: one memory round trip per phase
+    float4 a[4], vr[2][2];
+    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* xr = h + (long long)ri * D + q * 4;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = ld_coh4(xr + min(w + u * SW, nchunk - 1) * 16);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int rr = min(w + SW * k, M - 1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int c = lane + 64 * e;
+          vr[k][e] = c < nch4 ? ld_coh4(h + (long long)rr * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+      if (w == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = ld_coh(h + (long long)min(q * 4 + r, M - 1) * D + n);
+      }
+    }
     // ---- statistics of both LayerNorms, one wave per row (rows w, w + 8)
-    for (int row = w; row < 16; row += SW) {
-      const int rr = min(row, M - 1);
-      float4 v[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = w + SW * k;
+      float4 v[2] = {vr[k][0], vr[k][1]};
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int c = lane + 64 * e;
-        v[e] = c < nch4 ? ld_coh4(h + (long long)rr * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
-      }
+      for (int e = 0; e < 2; ++e) s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         const float* gp = pass == 0 ? P.g1 : P.g2;
@@ -172,8 +190,8 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
 #pragma unroll
         for (int e = 0; e < 2; ++e)
           if (lane + 64 * e < nch4) {
-            const float a = v[e].x - mean, bb = v[e].y - mean, c2 = v[e].z - mean, d = v[e].w - mean;
-            qq += (a * a + bb * bb) + (c2 * c2 + d * d);
+            const float a_ = v[e].x - mean, bb = v[e].y - mean, c2 = v[e].z - mean, d = v[e].w - mean;
+            qq += (a_ * a_ + bb * bb) + (c2 * c2 + d * d);
           }
         const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)D + eps);
         if (lane == 0) { st[row][2 * pass] = mean; st[row][2 * pass + 1] = rstd; }
@@ -202,13 +220,11 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
     // ---- a = relu(u W1^T + c1)
     {
       const float m1 = st[i][0], r1 = st[i][1], m2 = st[i][2], r2 = st[i][3];
-      const float* xr = h + (long long)ri * D + q * 4;
-      float4 a[4], G1[4], B1[4], G2[4], B2[4];
+      float4 G1[4], B1[4], G2[4], B2[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int c = min(w + u * SW, nchunk - 1);
         const int ko = c * 16 + q * 4;
-        a[u] = ld_coh4(xr + c * 16);
         G1[u] = *(const float4*)(P.g1 + ko); B1[u] = *(const float4*)(P.b1 + ko);
         G2[u] = *(const float4*)(P.g2 + ko); B2[u] = *(const float4*)(P.b2 + ko);
       }
@@ -248,8 +264,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
         for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
         v = fmaxf(v + bv, 0.f);
         st_coh(A + blk * MD + (long long)m * D + n, v);
-        const float hv = ld_coh(h + (long long)m * D + n);
-        x1v[r] = (hv - st[m][0]) * st[m][1] * g1n + b1n;
+        x1v[r] = (hv[r] - st[m][0]) * st[m][1] * g1n + b1n;
       }
     }
     if (!grid_arrive_wait(gb, ++epoch)) return;
@@ -389,21 +404,45 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
         st_coh(DU + blk * MD + (long long)m * D + c, v);
       }
     }
+    // operands of the LayerNorm backward that do not cross workgroups: fetched while waiting for du
+    const float* hin = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
+    const float* stp = ST + (long long)blk * 4 * M;
+    float4 zx1[2][2], zh[2][2];
+    float sm[2][4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = min(w + SW * k, M - 1);
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) sm[k][t4] = stp[t4 * M + row];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ch = min(lane + 64 * e, nch4 - 1);
+        zx1[k][e] = *(const float4*)(X1 + blk * MD + (long long)row * D + ch * 4);
+        zh[k][e] = *(const float4*)(hin + (long long)row * D + ch * 4);
+      }
+    }
     if (!grid_arrive_wait(gb, ++epoch)) return;
     // ---- panel <- LN1'(panel + LN2'(du)), rows w, w + 8
     {
-      const float* hin = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
-      const float* stp = ST + (long long)blk * 4 * M;
-      for (int row = w; row < M; row += SW) {
-        const float m1 = stp[row], r1 = stp[M + row], m2 = stp[2 * M + row], r2 = stp[3 * M + row];
+      float4 dun[2][2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+          dun[k][e] = ld_coh4(DU + blk * MD + (long long)min(w + SW * k, M - 1) * D + min(lane + 64 * e, nch4 - 1) * 4);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = w + SW * k;
+        if (row >= M) continue;
+        const float m1 = sm[k][0], r1 = sm[k][1], m2 = sm[k][2], r2 = sm[k][3];
         float4 xh[2], dgv[2], d1[2];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int ch = lane + 64 * e;
           if (ch < nch4) {
-            const float4 zz = *(const float4*)(X1 + blk * MD + (long long)row * D + ch * 4);
-            const float4 d = ld_coh4(DU + blk * MD + (long long)row * D + ch * 4);
+            const float4 zz = zx1[k][e];
+            const float4 d = dun[k][e];
             const float4 gm = *(const float4*)(P.g2 + ch * 4);
             xh[e] = make_float4((zz.x - m2) * r2, (zz.y - m2) * r2, (zz.z - m2) * r2, (zz.w - m2) * r2);
             dgv[e] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
@@ -424,7 +463,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             const float4 ee = *(const float4*)(panel + row * D + ch * 4);
             d1[e].x += ee.x; d1[e].y += ee.y; d1[e].z += ee.z; d1[e].w += ee.w;
             if (blockIdx.x == 0) *(float4*)(DX1 + blk * MD + (long long)row * D + ch * 4) = d1[e];
-            const float4 zz = *(const float4*)(hin + (long long)row * D + ch * 4);
+            const float4 zz = zh[k][e];
             const float4 gm = *(const float4*)(P.g1 + ch * 4);
             xh[e] = make_float4((zz.x - m1) * r1, (zz.y - m1) * r1, (zz.z - m1) * r1, (zz.w - m1) * r1);
             dgv[e] = make_float4(d1[e].x * gm.x, d1[e].y * gm.y, d1[e].z * gm.z, d1[e].w * gm.w);
