@@ -191,18 +191,21 @@ int ser_linear_fwd_ln2(const float* x, const float* W, const float* bias, int ac
  * :209-216 the 35-block loop), for M <= 16 rows and D <= 512 (a multiple of 16):
  *   x1 = LN(h; g1,b1)   u = LN(x1; g2,b2)   a = relu(u W1^T + c1)   h' = x1 + a W2^T + c2.
  * D/16 resident workgroups own 16 output columns each and hand the M x D activations to each other through
- * device memory (coherent loads / stores + one epoch word per workgroup, bounded waits).
+ * device memory as (value, tag) pairs: one 8-byte coherent store per element whose tag names the producing phase;
+ * consumers re-read until the tags match (bounded), so a hand-off has no flag, fence or barrier.
  * ptr_table  : device array [L][8] of parameter pointers {g1,b1,g2,b2,W1,c1,W2,c2} per block
  * grad_table : device array [L][4] of gradient pointers {dg1,db1,dg2,db2} per block
- * flags      : >= 65 device words of scratch per launch (zeroed by the call)
+ * scratch    : ser_stack_scratch_bytes(D) bytes per direction, 256-byte aligned, zeroed ONCE at allocation
+ *              (word 0 counts launches, word 1 is a sticky "wait abandoned" flag, then the exchange ring)
  * Hs[L][M][D] block outputs, X1/U/A[L][M][D] and ST[L][4][M] saved for backward.
  * ser_stack_bwd: DH[L+1][M][D], DH[L] = gradient at the stack output on entry; on return DH[i] = gradient at the input
  * of block i; DA/DU/DX1[L][M][D] feed ser_linear_wgrad_batch and ser_stack_ln_param_bwd. */
 int ser_stack_supported(int L, int M, int D);
+size_t ser_stack_scratch_bytes(int D);
 int ser_stack_fwd(const void* ptr_table, const float* x0, float* Hs, float* X1, float* U, float* A, float* ST, int L,
-                  int M, int D, float eps, void* flags, void* stream);
+                  int M, int D, float eps, void* scratch, void* stream);
 int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const float* X1, const float* A,
-                  const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* flags,
+                  const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* scratch,
                   void* stream);
 int ser_stack_ln_param_bwd(const void* grad_table, const float* x0, const float* Hs, const float* X1, const float* ST,
                            const float* DU, const float* DX1, int L, int M, int D, int accumulate, void* stream);

@@ -110,8 +110,7 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float mx = fmaxf(fmaxf(sc[0][r], sc[1][r]), fmaxf(sc[2][r], sc[3][r]));
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      mx = row16_max(mx);
       const float mn = fmaxf(m[r], mx);
       const float mu = mn == -INFINITY ? 0.f : mn;
       alpha[r] = __expf(m[r] - mu);
@@ -122,8 +121,7 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
         sc[j][r] = p;
         ps += p;
       }
-#pragma unroll
-      for (int off = 8; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+      ps = row16_sum(ps);
       l[r] = l[r] * alpha[r] + ps;
       m[r] = mn;
     }

@@ -111,39 +111,110 @@ __global__ __launch_bounds__(512) void barrier_probe_kernel(GridBar gb, float* d
 // The residual stack of the deep classifier (ref classifier.py:77-89 DeepResidualBlock, :209-216 the loop):
 //   x1 = LN(h; g1,b1)   u = LN(x1; g2,b2)   a = relu(u W1^T + c1)   h' = x1 + a W2^T + c2
 // at M <= 16 rows.  One launch walks all L blocks: workgroup b owns output columns [16 b, 16 b + 16) of every
-// Linear (its weight slice is fetched into registers before the hand-off wait), the M x D activations are exchanged
-// through device memory with the coherent accesses above, two hand-offs per block.  Arithmetic and summation order
-// are those of skinny_fwd_ln2_kernel / skinny_fwd_kernel (gemm_f32.hip), so results are bit-identical to the
-// one-launch-per-Linear path.
+// Linear (its weight slice is fetched one phase ahead), and the M x D activations travel between workgroups as
+// (value, tag) pairs: every element is ONE 8-byte coherent store whose upper half carries the number of the
+// phase that produced it, and a consumer simply re-reads the elements it needs until their tags match.  There is
+// no flag, no fence and no barrier on the path: a hand-off costs one store and one load latency.  The exchange
+// area is a two-slot ring (a slot is rewritten two phases later, which the data dependencies already order);
+// tags are unique per launch (launch counter in the scratch area), so nothing is reset between launches.
+// Dense copies of everything backward needs are written on the side with ordinary stores.
+// Arithmetic and summation order are those of skinny_fwd_ln2_kernel / skinny_fwd_kernel /
+// skinny_dgrad16_kernel / ln2_bwd_kernel.
 // ------------------------------------------------------------------------------------------
 struct StackBlockPtrs {
   const float *g1, *b1, *g2, *b2, *W1, *c1, *W2, *c2;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long ull;
 
-SER_DEVFN float4 ld_coh4(const float* p) {
-  const float2 lo = ld_coh2(p), hi = ld_coh2(p + 2);
-  return make_float4(lo.x, lo.y, hi.x, hi.y);
+constexpr int SW = 8;            // waves per workgroup
+constexpr int PPAD = 4;          // LDS panel row padding (floats): rows land on different banks
+constexpr unsigned LL_SPIN_LIMIT = 1u << 20;
+
+// optional phase timestamps of workgroup 0 (scripts/stack_timeline.py): [L][8] wall-clock ticks (10 ns)
+__device__ unsigned long long* g_stack_dbg = nullptr;
+#define STACK_MARK(k)                                                                       \
+  do {                                                                                      \
+    if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[blk * 8 + (k)] = wall_clock64();   \
+  } while (0)
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// store of the wave (s_waitcnt vmcnt(0)), i.e. the weight prefetch and the dense side copies would sit on the
+// critical path of every phase; nothing in these kernels communicates through global memory inside a workgroup.
+SER_DEVFN void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct StackScratch {            // device scratch of one direction: 256-byte header + ring[2][16][D] of (value, tag)
+  unsigned* launch;              // [0] launches so far
+  unsigned* abort;               // [1] sticky: a wait was abandoned
+  ull* ring;
+};
+SER_DEVFN StackScratch stack_scratch(void* p) {
+  return StackScratch{(unsigned*)p, (unsigned*)p + 1, (ull*)((char*)p + 256)};
 }
 
-constexpr int SW = 8;   // waves per workgroup
+SER_DEVFN void st_ll(ull* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((ull)tag << 32) | (ull)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Copy the first M rows of a ring slot into the LDS panel [16][D + PPAD], waiting for tag `want` on every element.
+// 512 threads; returns false (for the whole workgroup) when the wait was abandoned.
+SER_DEVFN bool ll_fetch_panel(const ull* slot, float* panel, int M, int D, unsigned want, unsigned* abort_flag) {
+  __shared__ int ll_ok;
+  if (threadIdx.x == 0) ll_ok = 1;
+  lds_barrier();
+  bool ok = true;
+  for (int col = threadIdx.x; col < D && ok; col += SW * 64) {
+    unsigned spins = 0;
+    for (;;) {
+      ull u[16];                                         // all (<= 16) rows of this column in one round trip
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        u[k] = __hip_atomic_load(slot + min(k, M - 1) * D + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool good = true;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) good = good && ((unsigned)(u[k] >> 32) == want);
+      if (good) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < M) panel[k * (D + PPAD) + col] = __uint_as_float((unsigned)u[k]);
+        break;
+      }
+      if (++spins > LL_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  if (!ok) ll_ok = 0;
+  lds_barrier();
+  return ll_ok != 0;
+}
 
 __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs* __restrict__ tab, const float* __restrict__ x0,
-                                                            float* Hs, float* __restrict__ X1, float* __restrict__ U,
-                                                            float* A, float* __restrict__ ST, int L, int M, int D, float eps,
-                                                            GridBar gb) {
+                                                            float* __restrict__ Hs, float* __restrict__ X1,
+                                                            float* __restrict__ U, float* __restrict__ A,
+                                                            float* __restrict__ ST, int L, int M, int D, float eps,
+                                                            void* scratch) {
+  extern __shared__ float lds_dyn[];
   __shared__ float red[SW][64][4];
   __shared__ float st[16][4];
+  const StackScratch sc = stack_scratch(scratch);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16, n = n0 + i;
-  const int nch4 = D >> 2, nchunk = D >> 4;
+  const int nch4 = D >> 2, nchunk = D >> 4, PD = D + PPAD;
+  float* panel = lds_dyn;                             // [16][PD]  block input h, then a
+  float* upan = lds_dyn + 16 * PD;                    // [16][PD]  u = LN(LN(h))
   const int nit = (nchunk - w + SW - 1) / SW;          // <= 4 (D <= 512)
   const long long MD = (long long)M * D;
   const int ri = min(i, M - 1);
-  unsigned epoch = 0;
-  float4 b[4];
+  const unsigned tagbase = (*sc.launch + 1u) << 12;
+  const long long slot_elems = (long long)16 * D;
+  unsigned long long* dbg = g_stack_dbg;
+  float4 b[4], bn[4];
   {
     const float* wr = tab[0].W1 + (long long)n * D + q * 4;
 #pragma unroll
@@ -151,40 +222,49 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
   }
   for (int blk = 0; blk < L; ++blk) {
     const StackBlockPtrs P = tab[blk];
-    const float* h = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
-    // every load that crosses workgroups is issued here, back to back: one memory round trip per phase
-    float4 a[4], vr[2][2];
-    float hv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int pA = 2 * blk, pB = 2 * blk + 1;          // phase numbers; phase p writes slot p & 1 with tag tagbase + p + 1
+    // weight slice of the second Linear: a whole phase ahead of its use
     {
-      const float* xr = h + (long long)ri * D + q * 4;
+      const float* wr = P.W2 + (long long)n * D + q * 4;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = ld_coh4(xr + min(w + u * SW, nchunk - 1) * 16);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int rr = min(w + SW * k, M - 1);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int c = lane + 64 * e;
-          vr[k][e] = c < nch4 ? ld_coh4(h + (long long)rr * D + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-      if (w == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = ld_coh(h + (long long)min(q * 4 + r, M - 1) * D + n);
-      }
+      for (int u = 0; u < 4; ++u) bn[u] = *(const float4*)(wr + min(w + u * SW, nchunk - 1) * 16);
     }
+    // small per-block parameters: requested before the hand-off wait, used after it
+    float4 pg[2][2], pb[2][2];                          // [LayerNorm][chunk of this lane]
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int c = min(lane + 64 * e, nch4 - 1);
+      pg[0][e] = *(const float4*)(P.g1 + c * 4); pb[0][e] = *(const float4*)(P.b1 + c * 4);
+      pg[1][e] = *(const float4*)(P.g2 + c * 4); pb[1][e] = *(const float4*)(P.b2 + c * 4);
+    }
+    const float c1n = P.c1[n], g1n = P.g1[n], b1n = P.b1[n], c2n = P.c2[n];
+    STACK_MARK(0);
+    // ---- block input -> LDS panel
+    if (blk == 0) {
+      for (int idx = threadIdx.x; idx < M * nch4; idx += SW * 64) {
+        const float4 v = ((const float4*)x0)[idx];
+        *(float4*)(panel + (idx / nch4) * PD + (idx % nch4) * 4) = v;
+      }
+      lds_barrier();
+    } else {
+      if (!ll_fetch_panel(sc.ring + ((pA - 1) & 1) * slot_elems, panel, M, D, tagbase + pA, sc.abort)) return;
+    }
+    STACK_MARK(1);
     // ---- statistics of both LayerNorms, one wave per row (rows w, w + 8)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int row = w + SW * k;
-      float4 v[2] = {vr[k][0], vr[k][1]};
+      const int rr = min(row, M - 1);
+      float4 v[2];
       float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+      for (int e = 0; e < 2; ++e) {
+        const int c = lane + 64 * e;
+        v[e] = c < nch4 ? *(const float4*)(panel + rr * PD + c * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+      }
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
-        const float* gp = pass == 0 ? P.g1 : P.g2;
-        const float* bp = pass == 0 ? P.b1 : P.b2;
         const float mean = wave_sum(s) / (float)D;
         float qq = 0.f;
 #pragma unroll
@@ -200,42 +280,32 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
         for (int e = 0; e < 2; ++e) {
           const int c = lane + 64 * e;
           if (c < nch4) {
-            const float4 gm = *(const float4*)(gp + c * 4), bt = *(const float4*)(bp + c * 4);
+            const float4 gm = pg[pass][e], bt = pb[pass][e];
             float4 o;
             o.x = (v[e].x - mean) * rstd * gm.x + bt.x; o.y = (v[e].y - mean) * rstd * gm.y + bt.y;
             o.z = (v[e].z - mean) * rstd * gm.z + bt.z; o.w = (v[e].w - mean) * rstd * gm.w + bt.w;
             if (blockIdx.x == 0 && row < M)
               *(float4*)((pass == 0 ? X1 : U) + blk * MD + (long long)row * D + c * 4) = o;
+            if (pass == 1) *(float4*)(upan + row * PD + c * 4) = o;
             v[e] = o;
             s += (o.x + o.y) + (o.z + o.w);
           }
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (blockIdx.x == 0 && threadIdx.x < 64) {
       const int row = threadIdx.x >> 2, which = threadIdx.x & 3;
       if (row < M) ST[(long long)blk * 4 * M + which * M + row] = st[row][which];
     }
+    STACK_MARK(2);
     // ---- a = relu(u W1^T + c1)
     {
-      const float m1 = st[i][0], r1 = st[i][1], m2 = st[i][2], r2 = st[i][3];
-      float4 G1[4], B1[4], G2[4], B2[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c = min(w + u * SW, nchunk - 1);
-        const int ko = c * 16 + q * 4;
-        G1[u] = *(const float4*)(P.g1 + ko); B1[u] = *(const float4*)(P.b1 + ko);
-        G2[u] = *(const float4*)(P.g2 + ko); B2[u] = *(const float4*)(P.b2 + ko);
-      }
+      const float* ur = upan + i * PD + q * 4;          // rows >= M hold copies of row M-1 (never stored)
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        float4 t;
-        t.x = (((a[u].x - m1) * r1 * G1[u].x + B1[u].x) - m2) * r2 * G2[u].x + B2[u].x;
-        t.y = (((a[u].y - m1) * r1 * G1[u].y + B1[u].y) - m2) * r2 * G2[u].y + B2[u].y;
-        t.z = (((a[u].z - m1) * r1 * G1[u].z + B1[u].z) - m2) * r2 * G2[u].z + B2[u].z;
-        t.w = (((a[u].w - m1) * r1 * G1[u].w + B1[u].w) - m2) * r2 * G2[u].w + B2[u].w;
+        float4 t = *(const float4*)(ur + min(w + u * SW, nchunk - 1) * 16);
         if (u >= nit) t = make_float4(0.f, 0.f, 0.f, 0.f);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.x, b[u].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t.y, b[u].y, acc, 0, 0, 0);
@@ -245,16 +315,12 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
     }
-    // weight slice of the second Linear: in flight during the reduction and the hand-off
-    {
-      const float* wr = P.W2 + (long long)n * D + q * 4;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) b[u] = *(const float4*)(wr + min(w + u * SW, nchunk - 1) * 16);
-    }
-    __syncthreads();
+    lds_barrier();
+    STACK_MARK(3);
     float x1v[4] = {0.f, 0.f, 0.f, 0.f};                 // residual operand of this thread's outputs (wave 0)
     if (w == 0) {
-      const float bv = P.c1[n], g1n = P.g1[n], b1n = P.b1[n];
+      const float bv = c1n;
+      ull* slot = sc.ring + (pA & 1) * slot_elems;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = q * 4 + r;
@@ -263,37 +329,41 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
 #pragma unroll
         for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
         v = fmaxf(v + bv, 0.f);
-        st_coh(A + blk * MD + (long long)m * D + n, v);
-        x1v[r] = (hv[r] - st[m][0]) * st[m][1] * g1n + b1n;
+        st_ll(slot + m * D + n, v, tagbase + pA + 1);
+        A[blk * MD + (long long)m * D + n] = v;
+        x1v[r] = (panel[m * PD + n] - st[m][0]) * st[m][1] * g1n + b1n;
       }
     }
-    if (!grid_arrive_wait(gb, ++epoch)) return;
-    // ---- h' = x1 + a W2^T + c2
-    {
-      const float* ar = A + blk * MD + (long long)ri * D + q * 4;
-      float4 a[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = ld_coh4(ar + min(w + u * SW, nchunk - 1) * 16);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (u >= nit) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
-    }
+    // next block's first weight slice (used two phases from now)
     if (blk + 1 < L) {
       const float* wr = tab[blk + 1].W1 + (long long)n * D + q * 4;
 #pragma unroll
       for (int u = 0; u < 4; ++u) b[u] = *(const float4*)(wr + min(w + u * SW, nchunk - 1) * 16);
     }
-    __syncthreads();
+    STACK_MARK(4);
+    // ---- h' = x1 + a W2^T + c2
+    if (!ll_fetch_panel(sc.ring + (pA & 1) * slot_elems, panel, M, D, tagbase + pA + 1, sc.abort)) return;
+    STACK_MARK(5);
+    {
+      const float* ar = panel + ri * PD + q * 4;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float4 a = *(const float4*)(ar + min(w + u * SW, nchunk - 1) * 16);
+        if (u >= nit) a = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bn[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bn[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bn[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bn[u].w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+    lds_barrier();
+    STACK_MARK(6);
     if (w == 0) {
-      const float bv = P.c2[n];
+      const float bv = c2n;
+      ull* slot = sc.ring + (pB & 1) * slot_elems;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = q * 4 + r;
@@ -303,26 +373,35 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
         for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
         v = v + bv;
         v += x1v[r];
-        st_coh(Hs + blk * MD + (long long)m * D + n, v);
+        if (blk + 1 < L) st_ll(slot + m * D + n, v, tagbase + pB + 1);
+        Hs[blk * MD + (long long)m * D + n] = v;
       }
     }
-    if (!grid_arrive_wait(gb, ++epoch)) return;
+    STACK_MARK(7);
+    lds_barrier();                                   // `red` and the panel are rewritten by the next block
   }
+  // every workgroup has read the launch counter before any can get here
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sc.launch = *sc.launch + 1u;
 }
 
 // Backward of the same stack.  Per block (last first), with dh' the gradient at the block output:
 //   da = (dh' W2) * relu'(a)      du = da W1      dx1 = dh' + LN2'(du)      dh = LN1'(dx1)
 // Workgroup b owns columns [16 b, 16 b + 16) of da and du (the reduction over the rows of W is split over the waves,
 // as in skinny_dgrad16_kernel); dh' lives in an LDS panel that every workgroup recomputes from du (row-wise
-// LayerNorm backward, one wave per row, as ln2_bwd_kernel).  Two hand-offs per block.  dh', da, du and dx1 of
-// every block are kept for the batched weight / LayerNorm-parameter gradients issued after this kernel.
+// LayerNorm backward, one wave per row, as ln2_bwd_kernel).  Two tagged hand-offs per block (da, du).  dh', da, du
+// and dx1 of every block are kept for the batched weight / LayerNorm-parameter gradients issued after this kernel.
 __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs* __restrict__ tab, const float* __restrict__ x0,
                                                             const float* __restrict__ Hs, const float* __restrict__ X1,
                                                             const float* __restrict__ A, const float* __restrict__ ST,
-                                                            float* __restrict__ DH, float* DA, float* DU,
-                                                            float* __restrict__ DX1, int L, int M, int D, GridBar gb) {
-  extern __shared__ float panel[];                   // [16][D]  gradient at the current block's output
+                                                            float* __restrict__ DH, float* __restrict__ DA,
+                                                            float* __restrict__ DU, float* __restrict__ DX1, int L, int M,
+                                                            int D, void* scratch) {
+  extern __shared__ float lds_dyn[];
+  const int PD = D + PPAD;
+  float* panel = lds_dyn;                             // [16][PD]  gradient at the current block's output
+  float* xpan = lds_dyn + 16 * PD;                    // [16][PD]  da, then du, as they arrive
   __shared__ float red[SW][64][4];
+  const StackScratch sc = stack_scratch(scratch);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int c = blockIdx.x * 16 + i;                  // output column of this lane
@@ -331,80 +410,27 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
   const int nit = (nsteps - w + SW - 1) / SW;         // <= 16
   const long long MD = (long long)M * D;
   const int ri = min(i, M - 1);
-  unsigned epoch = 0;
-  for (int idx = threadIdx.x; idx < M * nch4; idx += SW * 64)
-    ((float4*)panel)[idx] = ((const float4*)(DH + (long long)L * MD))[idx];
-  float bw[16];
+  const unsigned tagbase = (*sc.launch + 1u) << 12;
+  const long long slot_elems = (long long)16 * D;
+  for (int idx = threadIdx.x; idx < M * nch4; idx += SW * 64) {
+    const float4 v = ((const float4*)(DH + (long long)L * MD))[idx];
+    *(float4*)(panel + (idx / nch4) * PD + (idx % nch4) * 4) = v;
+  }
+  float bw[16], bw2[16];
   {
     const float* Wp = tab[L - 1].W2;
 #pragma unroll
     for (int u = 0; u < 16; ++u) bw[u] = Wp[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
   }
-  __syncthreads();
+  lds_barrier();
+  int phase = 0;
   for (int blk = L - 1; blk >= 0; --blk) {
     const StackBlockPtrs P = tab[blk];
-    // ---- da = (dh' W2) * relu'(a)
-    {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int p1 = phase, p2 = phase + 1;
+    phase += 2;
+    // weights of the second product and the local LayerNorm operands: a phase ahead of their use
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int nn = (w + u * SW) * 4 + q;
-        const float av = (u < nit && nn < D) ? panel[ri * D + min(nn, D - 1)] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[u], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) bw[u] = P.W1[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
-    __syncthreads();
-    if (w == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = q * 4 + r;
-        if (m >= M) continue;
-        float v = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
-        v = A[blk * MD + (long long)m * D + c] > 0.f ? v : 0.f;
-        st_coh(DA + blk * MD + (long long)m * D + c, v);
-      }
-    }
-    if (!grid_arrive_wait(gb, ++epoch)) return;
-    // ---- du = da W1
-    {
-      const float* dar = DA + blk * MD + (long long)ri * D;
-      float av[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) av[u] = ld_coh(dar + min((w + u * SW) * 4 + q, D - 1));
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int nn = (w + u * SW) * 4 + q;
-        const float a1 = (u < nit && nn < D) ? av[u] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw[u], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
-    }
-    if (blk > 0) {
-      const float* Wp = tab[blk - 1].W2;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) bw[u] = Wp[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
-    }
-    __syncthreads();
-    if (w == 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = q * 4 + r;
-        if (m >= M) continue;
-        float v = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
-        st_coh(DU + blk * MD + (long long)m * D + c, v);
-      }
-    }
-    // operands of the LayerNorm backward that do not cross workgroups: fetched while waiting for du
+    for (int u = 0; u < 16; ++u) bw2[u] = P.W1[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
     const float* hin = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
     const float* stp = ST + (long long)blk * 4 * M;
     float4 zx1[2][2], zh[2][2];
@@ -421,15 +447,78 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
         zh[k][e] = *(const float4*)(hin + (long long)row * D + ch * 4);
       }
     }
-    if (!grid_arrive_wait(gb, ++epoch)) return;
-    // ---- panel <- LN1'(panel + LN2'(du)), rows w, w + 8
+    float4 pg1[2], pg2[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int ch = min(lane + 64 * e, nch4 - 1);
+      pg1[e] = *(const float4*)(P.g1 + ch * 4);
+      pg2[e] = *(const float4*)(P.g2 + ch * 4);
+    }
+    float amask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) amask[r] = A[blk * MD + (long long)min(q * 4 + r, M - 1) * D + c];
+    // ---- da = (dh' W2) * relu'(a)
     {
-      float4 dun[2][2];
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
+      for (int u = 0; u < 16; ++u) {
+        const int nn = (w + u * SW) * 4 + q;
+        const float av = (u < nit && nn < D) ? panel[ri * PD + min(nn, D - 1)] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[u], acc, 0, 0, 0);
+      }
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-          dun[k][e] = ld_coh4(DU + blk * MD + (long long)min(w + SW * k, M - 1) * D + min(lane + 64 * e, nch4 - 1) * 4);
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+    lds_barrier();
+    if (w == 0) {
+      ull* slot = sc.ring + (p1 & 1) * slot_elems;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
+        v = amask[r] > 0.f ? v : 0.f;
+        st_ll(slot + m * D + c, v, tagbase + p1 + 1);
+        DA[blk * MD + (long long)m * D + c] = v;
+      }
+    }
+    if (blk > 0) {
+      const float* Wp = tab[blk - 1].W2;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) bw[u] = Wp[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
+    }
+    // ---- du = da W1
+    if (!ll_fetch_panel(sc.ring + (p1 & 1) * slot_elems, xpan, M, D, tagbase + p1 + 1, sc.abort)) return;
+    {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int nn = (w + u * SW) * 4 + q;
+        const float a1 = (u < nit && nn < D) ? xpan[ri * PD + min(nn, D - 1)] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bw2[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
+    }
+    lds_barrier();
+    if (w == 0) {
+      ull* slot = sc.ring + (p2 & 1) * slot_elems;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = q * 4 + r;
+        if (m >= M) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
+        st_ll(slot + m * D + c, v, tagbase + p2 + 1);
+        DU[blk * MD + (long long)m * D + c] = v;
+      }
+    }
+    // ---- panel <- LN1'(panel + LN2'(du)), rows w, w + 8
+    if (!ll_fetch_panel(sc.ring + (p2 & 1) * slot_elems, xpan, M, D, tagbase + p2 + 1, sc.abort)) return;
+    {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int row = w + SW * k;
@@ -442,8 +531,8 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
           const int ch = lane + 64 * e;
           if (ch < nch4) {
             const float4 zz = zx1[k][e];
-            const float4 d = dun[k][e];
-            const float4 gm = *(const float4*)(P.g2 + ch * 4);
+            const float4 d = *(const float4*)(xpan + row * PD + ch * 4);
+            const float4 gm = pg2[e];
             xh[e] = make_float4((zz.x - m2) * r2, (zz.y - m2) * r2, (zz.z - m2) * r2, (zz.w - m2) * r2);
             dgv[e] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
             s1 += (dgv[e].x + dgv[e].y) + (dgv[e].z + dgv[e].w);
@@ -460,11 +549,11 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             d1[e].y = r2 * (dgv[e].y - a1 - xh[e].y * a2);
             d1[e].z = r2 * (dgv[e].z - a1 - xh[e].z * a2);
             d1[e].w = r2 * (dgv[e].w - a1 - xh[e].w * a2);
-            const float4 ee = *(const float4*)(panel + row * D + ch * 4);
+            const float4 ee = *(const float4*)(panel + row * PD + ch * 4);
             d1[e].x += ee.x; d1[e].y += ee.y; d1[e].z += ee.z; d1[e].w += ee.w;
             if (blockIdx.x == 0) *(float4*)(DX1 + blk * MD + (long long)row * D + ch * 4) = d1[e];
             const float4 zz = zh[k][e];
-            const float4 gm = *(const float4*)(P.g1 + ch * 4);
+            const float4 gm = pg1[e];
             xh[e] = make_float4((zz.x - m1) * r1, (zz.y - m1) * r1, (zz.z - m1) * r1, (zz.w - m1) * r1);
             dgv[e] = make_float4(d1[e].x * gm.x, d1[e].y * gm.y, d1[e].z * gm.z, d1[e].w * gm.w);
             s1 += (dgv[e].x + dgv[e].y) + (dgv[e].z + dgv[e].w);
@@ -481,14 +570,15 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             o.y = r1 * (dgv[e].y - a1 - xh[e].y * a2);
             o.z = r1 * (dgv[e].z - a1 - xh[e].z * a2);
             o.w = r1 * (dgv[e].w - a1 - xh[e].w * a2);
-            *(float4*)(panel + row * D + ch * 4) = o;
+            *(float4*)(panel + row * PD + ch * 4) = o;
             if (blockIdx.x == 0) *(float4*)(DH + blk * MD + (long long)row * D + ch * 4) = o;
           }
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sc.launch = *sc.launch + 1u;
 }
 
 // LayerNorm-parameter gradients of all blocks in one launch (off the dgrad chain):
@@ -551,33 +641,31 @@ extern "C" int ser_stack_supported(int L, int M, int D) {
   return (L >= 1 && M >= 1 && M <= 16 && D >= 16 && D <= 512 && D % 16 == 0) ? 1 : 0;
 }
 
+extern "C" int ser_debug_stack_timeline(void* buf) {
+  unsigned long long* p = (unsigned long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stack_dbg), &p, sizeof(p)) == hipSuccess ? SER_OK : SER_E_HIP;
+}
+
+extern "C" size_t ser_stack_scratch_bytes(int D) { return 256 + (size_t)2 * 16 * D * sizeof(unsigned long long); }
+
 extern "C" int ser_stack_fwd(const void* ptr_table, const float* x0, float* Hs, float* X1, float* U, float* A, float* ST,
-                             int L, int M, int D, float eps, void* flags, void* stream) {
+                             int L, int M, int D, float eps, void* scratch, void* stream) {
   SER_TRY(stack_check(L, M, D));
-  hipStream_t st = (hipStream_t)stream;
-  GridBar gb{(unsigned*)flags, (unsigned*)flags + 64, D / 16};
-  if (hipMemsetAsync(flags, 0, 65 * sizeof(unsigned), st) != hipSuccess) {
-    ser_set_error("classifier stack: memset failed");
-    return SER_E_HIP;
-  }
-  hipLaunchKernelGGL(stack_fwd_kernel, dim3(D / 16), dim3(SW * 64), 0, st, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, U, A,
-                     ST, L, M, D, eps, gb);
+  SER_REQUIRE(scratch != nullptr && ((uintptr_t)scratch & 255) == 0, "classifier stack: scratch must be 256-byte aligned");
+  hipLaunchKernelGGL(stack_fwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)2 * 16 * (D + PPAD) * sizeof(float),
+                     (hipStream_t)stream, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, U, A, ST, L, M, D, eps, scratch);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
 
 extern "C" int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const float* X1, const float* A,
-                             const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* flags,
+                             const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* scratch,
                              void* stream) {
   SER_TRY(stack_check(L, M, D));
-  hipStream_t st = (hipStream_t)stream;
-  GridBar gb{(unsigned*)flags, (unsigned*)flags + 64, D / 16};
-  if (hipMemsetAsync(flags, 0, 65 * sizeof(unsigned), st) != hipSuccess) {
-    ser_set_error("classifier stack: memset failed");
-    return SER_E_HIP;
-  }
-  hipLaunchKernelGGL(stack_bwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)16 * D * sizeof(float), st,
-                     (const StackBlockPtrs*)ptr_table, x0, Hs, X1, A, ST, DH, DA, DU, DX1, L, M, D, gb);
+  SER_REQUIRE(scratch != nullptr && ((uintptr_t)scratch & 255) == 0, "classifier stack: scratch must be 256-byte aligned");
+  hipLaunchKernelGGL(stack_bwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)2 * 16 * (D + PPAD) * sizeof(float),
+                     (hipStream_t)stream, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, A, ST, DH, DA, DU, DX1, L, M, D,
+                     scratch);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

@@ -90,15 +90,41 @@ SER_DEVFN float gelu_erf(float x) {
   return x * (0.5f + copysignf(h, x));
 }
 
-SER_DEVFN float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the DPP path (a few cycles per step) instead of ds_bpermute shuffles (~100 cycles per
+// step through the LDS crossbar): lanes are combined inside their quad, then across the quads of a row of 16
+// (row_half_mirror, row_mirror), and the four row results are read with v_readlane.  Every step combines the same
+// two partial results on every lane, so all lanes end with identical bits.  Call with all 64 lanes active.
+template <int CTRL>
+SER_DEVFN float dpp_move(float v, float old) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                               0xf, 0xf, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140;
+
+SER_DEVFN float row16_sum(float v) {      // sum over the 16 lanes of a DPP row, result on every lane of the row
+  v += dpp_move<DPP_QUAD_XOR1>(v, 0.f);
+  v += dpp_move<DPP_QUAD_XOR2>(v, 0.f);
+  v += dpp_move<DPP_ROW_HALF_MIRROR>(v, 0.f);
+  v += dpp_move<DPP_ROW_MIRROR>(v, 0.f);
   return v;
 }
-SER_DEVFN float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+SER_DEVFN float row16_max(float v) {
+  v = fmaxf(v, dpp_move<DPP_QUAD_XOR1>(v, v));
+  v = fmaxf(v, dpp_move<DPP_QUAD_XOR2>(v, v));
+  v = fmaxf(v, dpp_move<DPP_ROW_HALF_MIRROR>(v, v));
+  v = fmaxf(v, dpp_move<DPP_ROW_MIRROR>(v, v));
   return v;
+}
+SER_DEVFN float lane_value(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+SER_DEVFN float wave_sum(float v) {
+  v = row16_sum(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+SER_DEVFN float wave_max(float v) {
+  v = row16_max(v);
+  return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -230,7 +230,8 @@ class AdvancedOpenMaxClassifier(nn.Module):
             dev = fp.flat.device
             tab = torch.tensor(rows, dtype=torch.int64).to(dev)
             gtab = torch.tensor(grows, dtype=torch.int64).to(dev)
-            flags = torch.zeros(2, 128, dtype=torch.int32, device=dev)
+            nb = int(O.L.lib.ser_stack_scratch_bytes(dc.base_dim))
+            flags = [torch.zeros(nb // 4, dtype=torch.int32, device=dev) for _ in range(2)]   # launch counter, abort word, ring
             self._stack_cache = (key, tab, gtab, flags)
         return self._stack_cache[1:]
 

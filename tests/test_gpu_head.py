@@ -267,7 +267,8 @@ def test_classifier_persistent_stack_equals_per_block_launches(M, rows, D, depth
 
     assert OP.stack_supported(depth, rows, D)
     a, b = run(True), run(False)
-    assert int(m._stack_cache[3][:, 64].abs().sum()) == 0, "a hand-off wait was abandoned"
+    assert all(int(sc[1]) == 0 for sc in m._stack_cache[3]), "a hand-off wait was abandoned"
+    assert all(int(sc[0]) >= 1 for sc in m._stack_cache[3]), "launch counters must advance"
     if D == 512:      # same K split over the waves as the launch-per-Linear kernels
         assert torch.equal(a[0], b[0]), f"logits differ by {(a[0] - b[0]).abs().max().item()}"
     else:
