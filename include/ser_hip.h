@@ -155,6 +155,15 @@ int ser_xlmr_forward(const SerXlmrConfig* cfg, const SerXlmrWeights* w, const in
                      const float* attn_mask, int B, int S, int prec, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Both frozen encoders in one call on one stream (audio_encoder.py:110 + text_encoder.py:55 of the same batch).
+ * With equal depth (Base 12 + 12) the transformer layers of the two models run in lock-step, ONE launch per step
+ * for both (grouped GEMM / attention / LayerNorm), instead of ~90 small XLM-R launches queueing behind the
+ * chip-filling Wav2Vec2 GEMMs on a second stream.  Same results and workspaces as the two separate calls. */
+int ser_encoders_forward(const SerW2vConfig* wcfg, const SerW2vWeights* ww, const float* wave, int B, int T,
+                         const SerXlmrConfig* xcfg, const SerXlmrWeights* xw, const int64_t* ids,
+                         const float* attn_mask, int Bt, int St, int prec, float* out_audio, float* out_text,
+                         void* ws_audio, size_t ws_audio_bytes, void* ws_text, size_t ws_text_bytes, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * trainable head, fp32 (forward and backward)

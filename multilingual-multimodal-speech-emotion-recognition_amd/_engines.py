@@ -188,3 +188,31 @@ class XlmrEngine:
                                        self.prec, out.data_ptr(), ws.data_ptr(), ws.numel(), L.stream_ptr()),
                 "ser_xlmr_forward")
         return out
+
+
+def forward_pair(audio_engine, text_engine, wave, ids, attn_mask):
+    """Both frozen encoders in ONE call on the current stream (ser_encoders_forward): when the two models have the
+    same depth their layers run in lock-step with one launch per step for both.  -> (a_enc [B,S_a,H], t_enc [B,S_t,H])."""
+    a, t = audio_engine, text_engine
+    assert a.prec == t.prec, "both encoders must run in the same precision mode"
+    assert wave.is_cuda and wave.dtype == torch.float32 and wave.dim() == 2
+    assert ids.is_cuda and ids.dtype == torch.int64
+    wave, ids = wave.contiguous(), ids.contiguous()
+    mask = attn_mask.to(torch.float32).contiguous()
+    B, T = wave.shape
+    Bt, St = ids.shape
+    Sa = a.out_len(T)
+    if Sa <= 0:
+        raise L.SerHipError(f"clip of {T} samples is shorter than the conv receptive field")
+    na = L.lib.ser_wav2vec2_workspace_bytes(C.byref(a.cfg), B, T, a.prec)
+    nt = L.lib.ser_xlmr_workspace_bytes(C.byref(t.cfg), Bt, St, t.prec)
+    if na == 0 or nt == 0:
+        L.check(-1, "ser_*_workspace_bytes")
+    wsa, wst = a.ws.get(na, wave.device), t.ws.get(nt, ids.device)
+    out_a = torch.empty(B, Sa, a.hidden, dtype=torch.float32, device=wave.device)
+    out_t = torch.empty(Bt, St, t.hidden, dtype=torch.float32, device=ids.device)
+    L.check(L.lib.ser_encoders_forward(C.byref(a.cfg), C.byref(a.w), wave.data_ptr(), B, T, C.byref(t.cfg), C.byref(t.w),
+                                       ids.data_ptr(), mask.data_ptr(), Bt, St, a.prec, out_a.data_ptr(), out_t.data_ptr(),
+                                       wsa.data_ptr(), wsa.numel(), wst.data_ptr(), wst.numel(), L.stream_ptr()),
+            "ser_encoders_forward")
+    return out_a, out_t

@@ -83,6 +83,8 @@ _sig("ser_wav2vec2_out_len", i32, C.POINTER(W2vConfig), i32)
 _sig("ser_wav2vec2_forward", i32, C.POINTER(W2vConfig), C.POINTER(W2vWeights), vp, i32, i32, i32, vp, vp, sz, vp)
 _sig("ser_xlmr_workspace_bytes", sz, C.POINTER(XlmrConfig), i32, i32, i32)
 _sig("ser_xlmr_forward", i32, C.POINTER(XlmrConfig), C.POINTER(XlmrWeights), vp, vp, i32, i32, i32, vp, vp, sz, vp)
+_sig("ser_encoders_forward", i32, C.POINTER(W2vConfig), C.POINTER(W2vWeights), vp, i32, i32, C.POINTER(XlmrConfig),
+     C.POINTER(XlmrWeights), vp, vp, i32, i32, i32, vp, vp, vp, sz, vp, sz, vp)
 
 
 def check(rc, what=""):

@@ -19,21 +19,29 @@ SER_DEVFN int tile_off(int row, int chunk) {
 }
 SER_DEVFN bf16x8 frag(const char* tile, int row, int chunk) { return *(const bf16x8*)(tile + tile_off(row, chunk)); }
 
+struct AttnProb {
+  const bf16_t *qkv_hi, *qkv_lo;
+  const float* key_mask;
+  int S, H;
+  bf16_t *ctx_hi, *ctx_lo;
+};
+
 template <bool X3>
-__global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __restrict__ qkv_hi,
-                                                             const bf16_t* __restrict__ qkv_lo,
-                                                             const float* __restrict__ key_mask, int S, int H,
-                                                             bf16_t* __restrict__ ctx_hi, bf16_t* __restrict__ ctx_lo) {
+SER_DEVFN void attn_body(const AttnProb& P, const int bx, const int head, const int b, char* lds) {
+  const bf16_t* __restrict__ qkv_hi = P.qkv_hi;
+  const bf16_t* __restrict__ qkv_lo = P.qkv_lo;
+  const float* __restrict__ key_mask = P.key_mask;
+  bf16_t* __restrict__ ctx_hi = P.ctx_hi;
+  bf16_t* __restrict__ ctx_lo = P.ctx_lo;
+  const int S = P.S, H = P.H;
   constexpr int NPL = X3 ? 2 : 1;
   constexpr int TILE = KC * 128;                       // 64 rows x 128 B
-  __shared__ __attribute__((aligned(1024))) char lds[NPL * TILE * 2 + 4 * NPL * 2048];
   char* Ks = lds;                                      // [NPL][64 key][64 d]
   char* Vt = lds + NPL * TILE;                         // [NPL][64 d][64 key]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* Ps = lds + NPL * TILE * 2 + wave * NPL * 2048; // [NPL][16 q][64 key]
   const int fr = lane & 15, fq = lane >> 4;
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 64 + wave * 16;
+  const int q0 = bx * 64 + wave * 16;
   const long long ld = 3LL * H;
   const bf16_t* plane[2] = {qkv_hi, qkv_lo};
 
@@ -180,7 +188,38 @@ __global__ __launch_bounds__(256) void self_attention_kernel(const bf16_t* __res
   }
 }
 
+template <bool X3>
+__global__ __launch_bounds__(256) void self_attention_kernel(const AttnProb P) {
+  __shared__ __attribute__((aligned(1024))) char lds[(X3 ? 2 : 1) * KC * 128 * 2 + 4 * (X3 ? 2 : 1) * 2048];
+  attn_body<X3>(P, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+}
+
+// two problems with the same (clips, heads) grid in one launch; the query tiles of problem 0 come first
+template <bool X3>
+__global__ __launch_bounds__(256) void self_attention_pair_kernel(const AttnProb P0, const AttnProb P1, const int qt0) {
+  __shared__ __attribute__((aligned(1024))) char lds[(X3 ? 2 : 1) * KC * 128 * 2 + 4 * (X3 ? 2 : 1) * 2048];
+  if ((int)blockIdx.x < qt0) attn_body<X3>(P0, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+  else attn_body<X3>(P1, blockIdx.x - qt0, blockIdx.y, blockIdx.z, lds);
+}
+
 }  // namespace
+
+int ser_launch_self_attention_pair(const SerAttnArgs& a, const SerAttnArgs& b, hipStream_t st) {
+  const bool x3 = a.qkv_lo && a.ctx_lo;
+  if (a.B != b.B || a.heads != b.heads || x3 != (b.qkv_lo && b.ctx_lo)) {
+    SER_TRY(ser_launch_self_attention(a.qkv_hi, a.qkv_lo, a.key_mask, a.B, a.S, a.heads, a.ctx_hi, a.ctx_lo, st));
+    return ser_launch_self_attention(b.qkv_hi, b.qkv_lo, b.key_mask, b.B, b.S, b.heads, b.ctx_hi, b.ctx_lo, st);
+  }
+  SER_REQUIRE(a.B > 0 && a.S > 0 && b.S > 0 && a.heads > 0, "self_attention: empty problem");
+  const int H = a.heads * HD, qt0 = ceil_div(a.S, 64);
+  const AttnProb P0{a.qkv_hi, x3 ? a.qkv_lo : nullptr, a.key_mask, a.S, H, a.ctx_hi, x3 ? a.ctx_lo : nullptr};
+  const AttnProb P1{b.qkv_hi, x3 ? b.qkv_lo : nullptr, b.key_mask, b.S, H, b.ctx_hi, x3 ? b.ctx_lo : nullptr};
+  dim3 grid(qt0 + ceil_div(b.S, 64), a.heads, a.B), block(256);
+  if (x3) hipLaunchKernelGGL(self_attention_pair_kernel<true>, grid, block, 0, st, P0, P1, qt0);
+  else hipLaunchKernelGGL(self_attention_pair_kernel<false>, grid, block, 0, st, P0, P1, qt0);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
 
 int ser_launch_self_attention(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const float* key_mask, int B, int S,
                               int heads, bf16_t* ctx_hi, bf16_t* ctx_lo, hipStream_t st) {
@@ -188,11 +227,13 @@ int ser_launch_self_attention(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const 
   SER_REQUIRE(qkv_hi && ctx_hi, "self_attention: null planes");
   const int H = heads * HD;
   dim3 grid(ceil_div(S, 64), heads, B), block(256);
-  if (qkv_lo && ctx_lo)
-    hipLaunchKernelGGL(self_attention_kernel<true>, grid, block, 0, st, qkv_hi, qkv_lo, key_mask, S, H, ctx_hi, ctx_lo);
-  else
-    hipLaunchKernelGGL(self_attention_kernel<false>, grid, block, 0, st, qkv_hi, (const bf16_t*)nullptr, key_mask, S, H,
-                       ctx_hi, (bf16_t*)nullptr);
+  if (qkv_lo && ctx_lo) {
+    const AttnProb P{qkv_hi, qkv_lo, key_mask, S, H, ctx_hi, ctx_lo};
+    hipLaunchKernelGGL(self_attention_kernel<true>, grid, block, 0, st, P);
+  } else {
+    const AttnProb P{qkv_hi, nullptr, key_mask, S, H, ctx_hi, nullptr};
+    hipLaunchKernelGGL(self_attention_kernel<false>, grid, block, 0, st, P);
+  }
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

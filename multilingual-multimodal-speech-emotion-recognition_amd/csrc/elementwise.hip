@@ -72,14 +72,25 @@ extern "C" int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long l
 // ------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row, row kept in registers (D <= 1024, D % 4 == 0)
 // ------------------------------------------------------------------------------------------
+struct LnProb {
+  const float *x, *x2, *gamma, *beta;
+  float eps;
+  int rows, D;
+  float* y;
+  bf16_t *yhi, *ylo;
+};
+
 template <int NV>  // float4 chunks per lane
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ x2,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float eps, int rows, int D, float* __restrict__ y,
-                                                        bf16_t* __restrict__ yhi, bf16_t* __restrict__ ylo) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+SER_DEVFN void ln_row(const LnProb& P, const int row, const int lane) {
+  const float* __restrict__ x = P.x;
+  const float* __restrict__ x2 = P.x2;
+  const float* __restrict__ gamma = P.gamma;
+  const float* __restrict__ beta = P.beta;
+  float* __restrict__ y = P.y;
+  bf16_t* __restrict__ yhi = P.yhi;
+  bf16_t* __restrict__ ylo = P.ylo;
+  const float eps = P.eps;
+  const int D = P.D;
   const int nchunk = D >> 2;
   const float* xr = x + (long long)row * D;
   const float* x2r = x2 ? x2 + (long long)row * D : nullptr;
@@ -134,17 +145,52 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnProb P) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P.rows) return;
+  ln_row<NV>(P, row, threadIdx.x & 63);
+}
+
+// rows of two independent problems in one launch (same D); problem 0 first
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_pair_kernel(const LnProb P0, const LnProb P1) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < P0.rows) ln_row<NV>(P0, row, threadIdx.x & 63);
+  else if (row - P0.rows < P1.rows) ln_row<NV>(P1, row - P0.rows, threadIdx.x & 63);
+}
+
 int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows,
                          int D, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
   SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d unsupported (need D %% 4 == 0, D <= 1024)", D);
   if (rows <= 0) return SER_OK;
   dim3 grid(ceil_div(rows, 4)), block(256);
   const int nv = ceil_div(D / 4, 64);
+  const LnProb P{x, x2, gamma, beta, eps, rows, D, y, yhi, ylo};
   switch (nv) {
-    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
-    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
-    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
-    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, x, x2, gamma, beta, eps, rows, D, y, yhi, ylo); break;
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, P); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, P); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, P); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, P); break;
+  }
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+int ser_launch_layernorm_pair(const SerLnArgs& a, const SerLnArgs& b, hipStream_t st) {
+  if (a.D != b.D || a.rows <= 0 || b.rows <= 0) {
+    SER_TRY(ser_launch_layernorm(a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo, st));
+    return ser_launch_layernorm(b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo, st);
+  }
+  SER_REQUIRE(a.D % 4 == 0 && a.D >= 4 && a.D <= 1024, "layernorm: D=%d unsupported", a.D);
+  const LnProb P0{a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo};
+  const LnProb P1{b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo};
+  dim3 grid(ceil_div(a.rows + b.rows, 4)), block(256);
+  switch (ceil_div(a.D / 4, 64)) {
+    case 1: hipLaunchKernelGGL(layernorm_pair_kernel<1>, grid, block, 0, st, P0, P1); break;
+    case 2: hipLaunchKernelGGL(layernorm_pair_kernel<2>, grid, block, 0, st, P0, P1); break;
+    case 3: hipLaunchKernelGGL(layernorm_pair_kernel<3>, grid, block, 0, st, P0, P1); break;
+    default: hipLaunchKernelGGL(layernorm_pair_kernel<4>, grid, block, 0, st, P0, P1); break;
   }
   SER_LAUNCH_CHECK();
   return SER_OK;
@@ -163,10 +209,17 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restric
   __shared__ double sh[2][16];
   const float* x = wave + (long long)blockIdx.x * T;
   double s = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < T; i += 1024) {
-    const double v = x[i];
-    s += v;
-    q += v * v;
+  for (int i0 = threadIdx.x; i0 < T; i0 += 8 * 1024) {     // eight independent loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = x[min(i0 + k * 1024, T - 1)];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i0 + k * 1024 < T) {
+        const double d = v[k];
+        s += d;
+        q += d * d;
+      }
   }
   for (int o = 32; o > 0; o >>= 1) {
     s += __shfl_xor(s, o, 64);
@@ -281,49 +334,27 @@ __global__ void conv0_finalize_kernel(const float2* __restrict__ partial, int ch
 // Fast path for a compile-time (KW, ST): the GroupNorm statistics never touch the conv output.
 // With y_t = sum_j w_j x_{ST t + j}:   sum_t y_t = w . S,   sum_t y_t^2 = w^T R w,   where
 // S_j = sum_t x_{ST t + j} and R_jk = sum_t x_{ST t + j} x_{ST t + k} depend on the clip only
-// (KW + KW (KW+1)/2 numbers).  One workgroup per clip computes the clip statistics, S and R on
-// the normalised samples, then mean / rstd of every channel in double precision.
+// (KW + KW (KW+1)/2 numbers).  Three small launches: clip statistics (wave_stats_kernel), partial S / R of the
+// normalised samples over C0_SLICES workgroups per clip, then mean / rstd of every channel in double precision.
 // ------------------------------------------------------------------------------------------
+constexpr int C0_SLICES = 8;     // workgroups per clip in the autocorrelation pass
+
+// partial S_j / R_jk of one slice of a clip's frames, on the normalised samples  ->  part[b][slice][NV] (double)
 template <int KW, int ST>
-__global__ __launch_bounds__(512) void conv0_stats_kernel(const float* __restrict__ wave, int T, int L0,
-                                                           const float* __restrict__ w, int C0,
-                                                           float2* __restrict__ wstats, float2* __restrict__ cstats) {
+__global__ __launch_bounds__(256) void conv0_acorr_kernel(const float* __restrict__ wave, const float2* __restrict__ wstats,
+                                                          int T, int L0, double* __restrict__ part) {
   constexpr int NR = KW * (KW + 1) / 2, NV = KW + NR;
-  __shared__ double red[8][NV];
-  __shared__ double tot[NV];
-  __shared__ double sh[2][8];
-  __shared__ float2 ws_sh;
-  const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  __shared__ float red[16][NV];                      // one entry per DPP row of 16 lanes (4 waves x 4 rows)
+  const int b = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x;
   const float* x = wave + (long long)b * T;
-  {
-    double s = 0.0, q = 0.0;
-    for (int i = tid; i < T; i += 512) {
-      const double v = x[i];
-      s += v;
-      q += v * v;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      s += __shfl_xor(s, o, 64);
-      q += __shfl_xor(q, o, 64);
-    }
-    if (lane == 0) { sh[0][wv] = s; sh[1][wv] = q; }
-    __syncthreads();
-    if (tid == 0) {
-      double ss = 0.0, qq = 0.0;
-      for (int i = 0; i < 8; ++i) { ss += sh[0][i]; qq += sh[1][i]; }
-      const double mean = ss / T;
-      double var = qq / T - mean * mean;
-      if (var < 0.0) var = 0.0;
-      ws_sh = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-7)));
-      wstats[b] = ws_sh;
-    }
-    __syncthreads();
-  }
-  const float m = ws_sh.x, r = ws_sh.y;
+  const float2 ws = wstats[b];
+  const float m = ws.x, r = ws.y;
+  const int per = (L0 + C0_SLICES - 1) / C0_SLICES;
+  const int t_end = min(L0, (sl + 1) * per);
   float acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-  for (int t = tid; t < L0; t += 512) {
+  for (int t = sl * per + tid; t < t_end; t += 256) {
     float xv[KW];
 #pragma unroll
     for (int j = 0; j < KW; ++j) xv[j] = (x[t * ST + j] - m) * r;
@@ -335,36 +366,51 @@ __global__ __launch_bounds__(512) void conv0_stats_kernel(const float* __restric
       for (int k = j; k < KW; ++k, ++idx) acc[idx] = fmaf(xv[j], xv[k], acc[idx]);
     }
   }
+  const int rowid = tid >> 4;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    double d = acc[i];
-    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-    if (lane == 0) red[wv][i] = d;
+    const float v = row16_sum(acc[i]);
+    if ((tid & 15) == 0) red[rowid][i] = v;
   }
   __syncthreads();
   if (tid < NV) {
     double d = 0.0;
-    for (int i = 0; i < 8; ++i) d += red[i][tid];
-    tot[tid] = d;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d += (double)red[i][tid];
+    part[((long long)b * C0_SLICES + sl) * NV + tid] = d;
+  }
+}
+
+// mean / rstd of every channel of a clip from the summed autocorrelation (double precision)
+template <int KW>
+__global__ __launch_bounds__(256) void conv0_cstats_kernel(const double* __restrict__ part, const float* __restrict__ w, int C0,
+                                                           int L0, float2* __restrict__ cstats) {
+  constexpr int NR = KW * (KW + 1) / 2, NV = KW + NR;
+  __shared__ double tot[NV];
+  const int b = blockIdx.y;
+  if (threadIdx.x < NV) {
+    double d = 0.0;
+    for (int sl = 0; sl < C0_SLICES; ++sl) d += part[((long long)b * C0_SLICES + sl) * NV + threadIdx.x];
+    tot[threadIdx.x] = d;
   }
   __syncthreads();
-  for (int c = tid; c < C0; c += 512) {
-    double wj[KW];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C0) return;
+  double wj[KW];
 #pragma unroll
-    for (int j = 0; j < KW; ++j) wj[j] = w[c * KW + j];
-    double s = 0.0, q = 0.0;
-    int idx = KW;
+  for (int j = 0; j < KW; ++j) wj[j] = w[c * KW + j];
+  double s = 0.0, q = 0.0;
+  int idx = KW;
 #pragma unroll
-    for (int j = 0; j < KW; ++j) {
-      s += wj[j] * tot[j];
+  for (int j = 0; j < KW; ++j) {
+    s += wj[j] * tot[j];
 #pragma unroll
-      for (int k = j; k < KW; ++k, ++idx) q += (k == j ? 1.0 : 2.0) * wj[j] * wj[k] * tot[idx];
-    }
-    const double mean = s / L0;
-    double var = q / L0 - mean * mean;
-    if (var < 0.0) var = 0.0;
-    cstats[(long long)b * C0 + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+    for (int k = j; k < KW; ++k, ++idx) q += (k == j ? 1.0 : 2.0) * wj[j] * wj[k] * tot[idx];
   }
+  const double mean = s / L0;
+  double var = q / L0 - mean * mean;
+  if (var < 0.0) var = 0.0;
+  cstats[(long long)b * C0 + c] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
 }
 
 typedef float ser_v2f __attribute__((ext_vector_type(2)));
@@ -417,9 +463,15 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
   }
 }
 
+// partial-sum area shared by the two statistics paths: generic [B][chunks][C0] float2, fast [B][C0_SLICES][<= 152] double
+static size_t conv0_partial_bytes(int B, int L0, int C0) {
+  const size_t generic = (size_t)B * ceil_div(L0, C0_FT) * C0 * sizeof(float2);
+  const size_t fast = (size_t)B * C0_SLICES * 152 * sizeof(double);
+  return ((generic > fast ? generic : fast) + 255) & ~(size_t)255;
+}
+
 size_t ser_conv0_scratch_bytes(int B, int L0, int C0) {
-  const int chunks = ceil_div(L0, C0_FT);
-  return (size_t)B * chunks * C0 * sizeof(float2) + (size_t)B * C0 * sizeof(float2) + (size_t)B * sizeof(float2) + 1024;
+  return conv0_partial_bytes(B, L0, C0) + (size_t)B * C0 * sizeof(float2) + (size_t)B * sizeof(float2) + 1024;
 }
 
 int ser_launch_conv0(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0,
@@ -429,10 +481,13 @@ int ser_launch_conv0(const float* wave, int B, int T, const float* w, const floa
   const int chunks = ceil_div(L0, C0_FT);
   char* p = (char*)scratch;
   float2* wstats = (float2*)p; p += (((size_t)B * sizeof(float2)) + 255) & ~(size_t)255;
-  float2* partial = (float2*)p; p += (size_t)B * chunks * C0 * sizeof(float2);
+  float2* partial = (float2*)p; p += conv0_partial_bytes(B, L0, C0);
   float2* cstats = (float2*)p;
   if (KW == 10 && ST == 5) {
-    hipLaunchKernelGGL((conv0_stats_kernel<10, 5>), dim3(B), dim3(512), 0, st, wave, T, L0, w, C0, wstats, cstats);
+    hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(1024), 0, st, wave, T, wstats);
+    hipLaunchKernelGGL((conv0_acorr_kernel<10, 5>), dim3(C0_SLICES, B), dim3(256), 0, st, wave, wstats, T, L0, (double*)partial);
+    hipLaunchKernelGGL((conv0_cstats_kernel<10>), dim3(ceil_div(C0, 256), B), dim3(256), 0, st, (const double*)partial, w, C0,
+                       L0, cstats);
     if (ylo)
       hipLaunchKernelGGL((conv0_apply_kernel<10, 5, true>), dim3(chunks, B), dim3(256), 0, st, wave, wstats, w, T, L0, C0,
                          cstats, gn_g, gn_b, yhi, ylo);

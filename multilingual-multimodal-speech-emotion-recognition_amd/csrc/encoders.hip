@@ -66,6 +66,96 @@ static int run_layer(const SerLayerW& w, const float* h, Planes hp, const float*
   return SER_OK;
 }
 
+// State of one encoder between its front end and its transformer layers (lets two encoders walk their layers
+// in lock-step with paired launches).
+struct LayerCtx {
+  const SerLayerW* layers;
+  int nlayers;
+  const float* key_mask;
+  int B, S, H, F, heads;
+  float eps;
+  float *hin, *hout;
+  Planes pin, pout;
+  LayerBufs lb;
+  float* out;
+};
+
+static SerLnArgs ln_args(const float* x, const float* g, const float* b, float eps, int rows, int D, float* y, Planes p) {
+  return SerLnArgs{x, nullptr, g, b, eps, rows, D, y, p.hi, p.lo};
+}
+
+// debug knob: which of the seven steps of a layer use the paired launch (bit i = step i); default all
+static int g_pair_mask = 0x7f;
+static int gemm_pair_or_not(int bit, const SerGemmArgs& s0, const SerGemmArgs& s1, hipStream_t st) {
+  if (g_pair_mask >> bit & 1) return ser_launch_gemm_bf16_pair(s0, s1, st);
+  SER_TRY(ser_launch_gemm_bf16(s0, st));
+  return ser_launch_gemm_bf16(s1, st);
+}
+static int ln_pair_or_not(int bit, const SerLnArgs& a, const SerLnArgs& b, hipStream_t st) {
+  if (g_pair_mask >> bit & 1) return ser_launch_layernorm_pair(a, b, st);
+  SER_TRY(ser_launch_layernorm(a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo, st));
+  return ser_launch_layernorm(b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo, st);
+}
+
+// Layer l of two encoders with one launch per step for both (a = the smaller problem, its tiles go first).
+static int run_layer_pair(LayerCtx& a, LayerCtx& b, int l, hipStream_t st) {
+  LayerCtx* cs[2] = {&a, &b};
+  SerGemmArgs g[2];
+  Planes none = {nullptr, nullptr};
+  const bool last = l == a.nlayers - 1;
+  for (int i = 0; i < 2; ++i) {
+    LayerCtx& c = *cs[i];
+    const SerLayerW& w = c.layers[l];
+    g[i] = gemm_args(c.pin, c.H, w.qkv, c.H, c.B * c.S, 3 * c.H, c.H);
+    g[i].bias = w.qkv_b; g[i].c_hi = c.lb.qkv.hi; g[i].c_lo = c.lb.qkv.lo; g[i].ldc = 3 * c.H;
+  }
+  SER_TRY(gemm_pair_or_not(0, g[0], g[1], st));
+  {
+    const SerAttnArgs aa{a.lb.qkv.hi, a.lb.qkv.lo, a.key_mask, a.B, a.S, a.heads, a.lb.ctx.hi, a.lb.ctx.lo};
+    const SerAttnArgs ab{b.lb.qkv.hi, b.lb.qkv.lo, b.key_mask, b.B, b.S, b.heads, b.lb.ctx.hi, b.lb.ctx.lo};
+    if (g_pair_mask >> 1 & 1) {
+      SER_TRY(ser_launch_self_attention_pair(aa, ab, st));
+    } else {
+      SER_TRY(ser_launch_self_attention(aa.qkv_hi, aa.qkv_lo, aa.key_mask, aa.B, aa.S, aa.heads, aa.ctx_hi, aa.ctx_lo, st));
+      SER_TRY(ser_launch_self_attention(ab.qkv_hi, ab.qkv_lo, ab.key_mask, ab.B, ab.S, ab.heads, ab.ctx_hi, ab.ctx_lo, st));
+    }
+  }
+  for (int i = 0; i < 2; ++i) {
+    LayerCtx& c = *cs[i];
+    const SerLayerW& w = c.layers[l];
+    g[i] = gemm_args(c.lb.ctx, c.H, w.o, c.H, c.B * c.S, c.H, c.H);
+    g[i].bias = w.o_b; g[i].residual = c.hin; g[i].ldr = c.H; g[i].c_f32 = c.lb.t1; g[i].ldc = c.H;
+  }
+  SER_TRY(gemm_pair_or_not(2, g[0], g[1], st));
+  SER_TRY(ln_pair_or_not(3, 
+      ln_args(a.lb.t1, a.layers[l].ln1_g, a.layers[l].ln1_b, a.eps, a.B * a.S, a.H, a.lb.h1, a.lb.h1p),
+      ln_args(b.lb.t1, b.layers[l].ln1_g, b.layers[l].ln1_b, b.eps, b.B * b.S, b.H, b.lb.h1, b.lb.h1p), st));
+  for (int i = 0; i < 2; ++i) {
+    LayerCtx& c = *cs[i];
+    const SerLayerW& w = c.layers[l];
+    g[i] = gemm_args(c.lb.h1p, c.H, w.f1, c.H, c.B * c.S, c.F, c.H);
+    g[i].bias = w.f1_b; g[i].act = SER_ACT_GELU; g[i].c_hi = c.lb.ffn.hi; g[i].c_lo = c.lb.ffn.lo; g[i].ldc = c.F;
+  }
+  SER_TRY(gemm_pair_or_not(4, g[0], g[1], st));
+  for (int i = 0; i < 2; ++i) {
+    LayerCtx& c = *cs[i];
+    const SerLayerW& w = c.layers[l];
+    g[i] = gemm_args(c.lb.ffn, c.F, w.f2, c.F, c.B * c.S, c.H, c.F);
+    g[i].bias = w.f2_b; g[i].residual = c.lb.h1; g[i].ldr = c.H; g[i].c_f32 = c.lb.t2; g[i].ldc = c.H;
+  }
+  SER_TRY(gemm_pair_or_not(5, g[0], g[1], st));
+  SER_TRY(ln_pair_or_not(6, 
+      ln_args(a.lb.t2, a.layers[l].ln2_g, a.layers[l].ln2_b, a.eps, a.B * a.S, a.H, last ? a.out : a.hout, last ? none : a.pout),
+      ln_args(b.lb.t2, b.layers[l].ln2_g, b.layers[l].ln2_b, b.eps, b.B * b.S, b.H, last ? b.out : b.hout, last ? none : b.pout),
+      st));
+  for (int i = 0; i < 2; ++i) {
+    LayerCtx& c = *cs[i];
+    float* tf = c.hin; c.hin = c.hout; c.hout = tf;
+    Planes tp = c.pin; c.pin = c.pout; c.pout = tp;
+  }
+  return SER_OK;
+}
+
 static int w2v_lengths(const SerW2vConfig* c, int T, int* L) {
   int len = T;
   for (int i = 0; i < c->n_conv; ++i) {
@@ -92,7 +182,7 @@ static int check_w2v_cfg(const SerW2vConfig* c) {
 
 // one pass over the arena; with ar.base == nullptr only the size is computed
 static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* wave, int B, int T, int prec, float* out,
-                   SerArena& ar, hipStream_t st, bool dry) {
+                   SerArena& ar, hipStream_t st, bool dry, LayerCtx* defer = nullptr) {
   const bool x3 = prec == SER_PREC_BF16X3;
   int L[SER_MAX_CONV];
   const int S = w2v_lengths(c, T, L);
@@ -162,6 +252,10 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
   SER_TRY(ser_launch_layernorm(hsum, nullptr, w->enc_ln_g, w->enc_ln_b, c->eps, (int)rows, H, ha, hpa.hi, hpa.lo, st));
   float* hin = ha; float* hout = hb;
   Planes pin = hpa, pout = hpb;
+  if (defer) {
+    *defer = LayerCtx{w->layers, c->layers, nullptr, B, S, H, F, c->heads, c->eps, hin, hout, pin, pout, lb, out};
+    return SER_OK;
+  }
   for (int l = 0; l < c->layers; ++l) {
     const bool last = l == c->layers - 1;
     Planes none = {nullptr, nullptr};
@@ -175,7 +269,7 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
 }
 
 static int xlmr_run(const SerXlmrConfig* c, const SerXlmrWeights* w, const int64_t* ids, const float* mask, int B, int S,
-                    int prec, float* out, SerArena& ar, hipStream_t st, bool dry) {
+                    int prec, float* out, SerArena& ar, hipStream_t st, bool dry, LayerCtx* defer = nullptr) {
   const bool x3 = prec == SER_PREC_BF16X3;
   const int H = c->hidden, F = c->ffn;
   const size_t rows = (size_t)B * S;
@@ -195,6 +289,10 @@ static int xlmr_run(const SerXlmrConfig* c, const SerXlmrWeights* w, const int64
                                 c->vocab, c->max_pos, c->pad_id, pos, ha, hpa.hi, hpa.lo, st));
   float* hin = ha; float* hout = hb;
   Planes pin = hpa, pout = hpb;
+  if (defer) {
+    *defer = LayerCtx{w->layers, c->layers, mask, B, S, H, F, c->heads, c->eps, hin, hout, pin, pout, lb, out};
+    return SER_OK;
+  }
   for (int l = 0; l < c->layers; ++l) {
     const bool last = l == c->layers - 1;
     Planes none = {nullptr, nullptr};
@@ -247,4 +345,36 @@ extern "C" int ser_xlmr_forward(const SerXlmrConfig* cfg, const SerXlmrWeights* 
   SER_REQUIRE(prec == SER_PREC_BF16 || prec == SER_PREC_BF16X3, "xlmr_forward: bad precision mode %d", prec);
   SerArena ar(workspace, workspace_bytes);
   return xlmr_run(cfg, w, ids, attn_mask, B, S, prec, out, ar, (hipStream_t)stream, false);
+}
+
+// Both frozen encoders in one call on one stream.  When they have the same depth (Base: 12 + 12, the stress
+// configuration: 24 + 24) their transformer layers run in lock-step with ONE launch per step for both models
+// (grouped GEMM / attention / LayerNorm launches, XLM-R's tiles first), instead of XLM-R's ~90 small dependent
+// launches queueing behind Wav2Vec2's chip-filling GEMMs on a second stream.  Results are those of the two
+// separate calls.
+extern "C" int ser_debug_set_pair_mask(int m) { g_pair_mask = m; return 0; }
+
+extern "C" int ser_encoders_forward(const SerW2vConfig* wcfg, const SerW2vWeights* ww, const float* wave, int B, int T,
+                                    const SerXlmrConfig* xcfg, const SerXlmrWeights* xw, const int64_t* ids,
+                                    const float* attn_mask, int Bt, int St, int prec, float* out_audio, float* out_text,
+                                    void* ws_audio, size_t ws_audio_bytes, void* ws_text, size_t ws_text_bytes,
+                                    void* stream) {
+  SER_TRY(check_w2v_cfg(wcfg));
+  SER_REQUIRE(ww && wave && out_audio && ws_audio && B > 0, "encoders_forward: null wav2vec2 argument");
+  SER_REQUIRE(xcfg && xw && ids && out_text && ws_text && Bt > 0 && St > 0, "encoders_forward: null xlmr argument");
+  SER_REQUIRE(xcfg->hidden == xcfg->heads * 64 && xcfg->hidden % 64 == 0 && xcfg->ffn % 64 == 0,
+              "xlmr: head_dim must be 64 and hidden/ffn multiples of 64");
+  SER_REQUIRE(prec == SER_PREC_BF16 || prec == SER_PREC_BF16X3, "encoders_forward: bad precision mode %d", prec);
+  hipStream_t st = (hipStream_t)stream;
+  SerArena ara(ws_audio, ws_audio_bytes), art(ws_text, ws_text_bytes);
+  if (wcfg->layers != xcfg->layers || wcfg->layers == 0) {
+    SER_TRY(xlmr_run(xcfg, xw, ids, attn_mask, Bt, St, prec, out_text, art, st, false));
+    return w2v_run(wcfg, ww, wave, B, T, prec, out_audio, ara, st, false);
+  }
+  LayerCtx ca, ct;
+  SER_TRY(xlmr_run(xcfg, xw, ids, attn_mask, Bt, St, prec, out_text, art, st, false, &ct));
+  SER_TRY(w2v_run(wcfg, ww, wave, B, T, prec, out_audio, ara, st, false, &ca));
+  const bool text_small = (long long)ct.B * ct.S <= (long long)ca.B * ca.S;
+  for (int l = 0; l < wcfg->layers; ++l) SER_TRY(text_small ? run_layer_pair(ct, ca, l, st) : run_layer_pair(ca, ct, l, st));
+  return SER_OK;
 }

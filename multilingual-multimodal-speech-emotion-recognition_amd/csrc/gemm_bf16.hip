@@ -247,6 +247,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g, 
   }
 }
 
+// Two independent problems in one launch (the layer-l GEMMs of Wav2Vec2 and of XLM-R have no dependence on each
+// other): the tiles of the small problem come first in the grid, so they start at once and ride along with the
+// large one instead of queueing, launch after launch, on a second stream behind it.
+template <int BM, int BN, bool X3>
+__global__ __launch_bounds__(256) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
+                                                             const int tiles0, const int tiles1) {
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3>::LDS_BYTES];
+  // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches
+  const bool first = (int)blockIdx.x < total0;
+  const SerGemmArgs* g = first ? &g0 : &g1;
+  const int w = first ? blockIdx.x : blockIdx.x - total0, tiles = first ? tiles0 : tiles1;
+  gemm_tile<BM, BN, X3>(*g, w % tiles, w / tiles, lds);
+}
+
 // ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
 struct ProfRec {
   hipEvent_t e0, e1;
@@ -285,7 +299,58 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
   return SER_OK;
 }
 
+template <int BM, int BN>
+int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) {
+  const int tiles0 = ceil_div(small.M, BM) * ceil_div(small.N, BN), tiles1 = ceil_div(big.M, BM) * ceil_div(big.N, BN);
+  const int total0 = tiles0 * small.nb1 * small.nb2, total1 = tiles1 * big.nb1 * big.nb2;
+  dim3 grid(total0 + total1), block(256);
+  ProfRec rec;
+  if (g_prof_on) {
+    SER_CHECK_HIP(hipEventCreate(&rec.e0));
+    SER_CHECK_HIP(hipEventCreate(&rec.e1));
+    rec.flops = 2.0 * small.M * (double)small.N * small.K * small.nb1 * small.nb2 +
+                2.0 * big.M * (double)big.N * big.K * big.nb1 * big.nb2;
+    SER_CHECK_HIP(hipEventRecord(rec.e0, st));
+  }
+  if (big.a_lo && big.w_lo)
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, true>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+  else
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+  if (g_prof_on) {
+    SER_CHECK_HIP(hipEventRecord(rec.e1, st));
+    g_prof.push_back(rec);
+  }
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+static int gemm_check(const SerGemmArgs& g) {
+  SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
+  SER_REQUIRE(g.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", g.K, BK);
+  SER_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm_bf16: lda=%d ldw=%d must be multiples of 8", g.lda, g.ldw);
+  SER_REQUIRE(g.a_hi && g.w_hi, "gemm_bf16: null operand");
+  SER_REQUIRE(g.nb1 >= 1 && g.nb2 >= 1, "gemm_bf16: bad batch");
+  return SER_OK;
+}
+
 }  // namespace
+
+// `big` decides the tile shape; both problems must be in the same precision mode.
+int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) {
+  SER_TRY(gemm_check(small));
+  SER_TRY(gemm_check(big));
+  SER_REQUIRE((small.a_lo && small.w_lo) == (big.a_lo && big.w_lo), "gemm_bf16 pair: mixed precision modes");
+  const long long nb = (long long)big.nb1 * big.nb2;
+  const long long t128 = (long long)ceil_div(big.M, 128) * ceil_div(big.N, 128) * nb;
+  if (big.N <= 64 || small.N <= 64) {          // keep the narrow-N shape out of the pair path
+    SER_TRY(ser_launch_gemm_bf16(small, st));
+    return ser_launch_gemm_bf16(big, st);
+  }
+  if (t128 >= 384 && big.M > 64) return launch_pair_cfg<128, 128>(small, big, st);
+  const long long t64 = (long long)ceil_div(big.M, 64) * ceil_div(big.N, 128) * nb;
+  if (t64 >= 256 || big.M <= 64) return launch_pair_cfg<64, 128>(small, big, st);
+  return launch_pair_cfg<64, 64>(small, big, st);
+}
 
 int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st) {
   SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
@@ -320,6 +385,18 @@ extern "C" int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int 
   g.c_f32 = c_f32; g.c_hi = c_hi; g.c_lo = c_lo; g.ldc = ldc;
   if ((a_lo == nullptr) != (w_lo == nullptr)) { g.a_lo = nullptr; g.w_lo = nullptr; }
   return ser_launch_gemm_bf16(g, (hipStream_t)stream);
+}
+
+// debug / test entry: two plain bf16 NT GEMMs (fp32 outputs) through the paired launch
+extern "C" int ser_debug_gemm_pair(const uint16_t* a0, const uint16_t* w0, int M0, int N0, int K0, float* c0,
+                                   const uint16_t* a1, const uint16_t* w1, int M1, int N1, int K1, float* c1, void* stream) {
+  SerGemmArgs g[2];
+  memset(g, 0, sizeof(g));
+  g[0].a_hi = a0; g[0].w_hi = w0; g[0].M = M0; g[0].N = N0; g[0].K = K0; g[0].lda = K0; g[0].ldw = K0;
+  g[0].nb1 = g[0].nb2 = 1; g[0].c_f32 = c0; g[0].ldc = N0;
+  g[1].a_hi = a1; g[1].w_hi = w1; g[1].M = M1; g[1].N = N1; g[1].K = K1; g[1].lda = K1; g[1].ldw = K1;
+  g[1].nb1 = g[1].nb2 = 1; g[1].c_f32 = c1; g[1].ldc = N1;
+  return ser_launch_gemm_bf16_pair(g[0], g[1], (hipStream_t)stream);
 }
 
 // Per-launch HIP-event timing of the encoder GEMM kernel.  start: begin recording; stop: synchronise

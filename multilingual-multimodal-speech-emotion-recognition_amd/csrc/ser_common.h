@@ -159,9 +159,25 @@ struct SerGemmArgs {
   int ldc;
 };
 int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st);
+int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st);
 int ser_launch_split(const float* x, bf16_t* hi, bf16_t* lo, long long n, hipStream_t st);
 int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows,
                          int D, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st);
+struct SerLnArgs {
+  const float *x, *x2, *gamma, *beta;
+  float eps;
+  int rows, D;
+  float* y;
+  bf16_t *yhi, *ylo;
+};
+int ser_launch_layernorm_pair(const SerLnArgs& a, const SerLnArgs& b, hipStream_t st);
+struct SerAttnArgs {
+  const bf16_t *qkv_hi, *qkv_lo;
+  const float* key_mask;
+  int B, S, heads;
+  bf16_t *ctx_hi, *ctx_lo;
+};
+int ser_launch_self_attention_pair(const SerAttnArgs& a, const SerAttnArgs& b, hipStream_t st);
 size_t ser_conv0_scratch_bytes(int B, int L0, int C0);
 int ser_launch_conv0(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0,
                      int KW, int ST, int L0, bf16_t* yhi, bf16_t* ylo, void* scratch, hipStream_t st);

@@ -102,3 +102,31 @@ def test_wav2vec2_generic_conv0_geometry(eng):
         got = e.forward(waves.cuda()).cpu()
         want = O.wav2vec2_forward(sd, torch.stack([O.normalise_waveform(w) for w in waves]), cfg)
         assert (got - want).abs().max().item() < 2e-4, (kernel, stride)
+
+
+@pytest.mark.parametrize("prec", ["x3", "bf16"])
+def test_paired_encoders_equal_separate_calls(eng, prec):
+    """ser_encoders_forward (layers of both models in lock-step, grouped launches) against the two separate
+    forwards: same per-element arithmetic, so the outputs must be identical."""
+    E, L = eng
+    sda, _, ra = split_fixture(load_npz("audio_encoder.npz"))
+    sdt, _, rt = split_fixture(load_npz("text_encoder.npz"))
+    ca, ct = cfg_of(ra), cfg_of(rt)
+    p = L.PREC_BF16X3 if prec == "x3" else L.PREC_BF16
+    ea = E.Wav2Vec2Engine(_w2v_hf_cfg(ca), O.sub(sda, "encoder."), "cuda", p)
+    et = E.XlmrEngine(_xlmr_hf_cfg(ct), O.sub(sdt, "encoder."), "cuda", p)
+    assert ca["layers"] == ct["layers"], "fixtures are expected to have equal depth (paired path)"
+    g = torch.Generator().manual_seed(11)
+    for B, T, St in ((3, 2400, 7), (2, 4000, 70), (5, 1700, 3)):
+        wave = (0.1 * torch.randn(B, T, generator=g)).cuda()
+        ids = torch.randint(4, ct["vocab"], (B, St), generator=g)
+        mask = torch.ones(B, St)
+        if St > 4:
+            ids[0, -2:] = ct["pad_id"]
+            mask[0, -2:] = 0
+        ids, mask = ids.cuda(), mask.cuda()
+        a1, t1 = ea.forward(wave), et.forward(ids, mask)
+        a2, t2 = E.forward_pair(ea, et, wave, ids, mask)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a2), f"audio differs by {(a1 - a2).abs().max().item()}"
+        assert torch.equal(t1, t2), f"text differs by {(t1 - t2).abs().max().item()}"
