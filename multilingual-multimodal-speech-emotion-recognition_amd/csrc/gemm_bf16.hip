@@ -26,17 +26,27 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // Stage R rows x 64 bf16 of a K-contiguous matrix into a swizzled LDS tile.
 // rows beyond `rmax` are clamped (their products are discarded by the epilogue).
+// The per-lane part of the source address is a 32-bit byte offset computed ONCE per tile (stage_offsets); per k-tile
+// only the wave-uniform base moves.  That keeps the address VGPRs of in-flight LDS-DMA instructions untouched, so
+// the compiler has no reason to drain the DMA queue (vmcnt(0)) before issuing the next stage.
 template <int R>
-SER_DEVFN void stage_tile(const bf16_t* __restrict__ base, long long ld, int row0, int rmax, int k0,
-                          char* lds_tile, int wave, int lane) {
+SER_DEVFN void stage_offsets(unsigned (&off)[R / 32], long long ld, int row0, int rmax, int wave, int lane) {
   const int r = lane >> 3;
   const int c = (lane & 7) ^ r;   // source chunk for LDS chunk position lane&7 of row r
 #pragma unroll
-  for (int i = 0; i < R / 32; ++i) {      // constant trip count: no scalar branches between the LDS-DMA issues
+  for (int i = 0; i < R / 32; ++i) {
     const int p = wave + 4 * i;
     int row = row0 + p * 8 + r;
     row = row < rmax ? row : rmax;
-    const bf16_t* src = base + (long long)row * ld + k0 + c * 8;
+    off[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
+  }
+}
+template <int R>
+SER_DEVFN void stage_tile(const bf16_t* __restrict__ base_k, const unsigned (&off)[R / 32], char* lds_tile, int wave) {
+#pragma unroll
+  for (int i = 0; i < R / 32; ++i) {      // constant trip count: no scalar branches between the LDS-DMA issues
+    const int p = wave + 4 * i;
+    const char* src = (const char*)base_k + off[i];
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + p * 1024), 16, 0, 0);
   }
 }
@@ -53,24 +63,33 @@ SER_DEVFN float apply_act(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, bool X3>
+template <int BM, int BN, bool X3, int NS = 2>
 struct GemmCfg {
   static constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
   static constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
   static constexpr int STAGE = (A_TILE + W_TILE) * NPL;
   static constexpr int EPI_BYTES = BM * (BN + 4) * 4;        // fp32 tile staged for the coalesced epilogue
-  static constexpr int LDS_RAW = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+  static constexpr int LDS_RAW = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+  static constexpr int GLDS = (BM / 32 + BN / 32) * NPL;       // LDS-DMA instructions per stage per wave
   // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
   // GEMMs on another stream, and a small workgroup that cannot get LDS waits for a whole GEMM workgroup to retire
   static constexpr int LDS_BYTES = LDS_RAW <= 32 * 1024 ? 34 * 1024 : LDS_RAW;
 };
 
 // one output tile; `bid` = tile index inside the (clip, group) batch entry `bz`
-template <int BM, int BN, bool X3>
+// wait until at most N of this wave's LDS-DMA instructions are still in flight, then a barrier that orders LDS only
+template <int N>
+SER_DEVFN void wait_dma_barrier() {
+  static_assert(N >= 0 && N < 64, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, bool X3, int NS = 2>
 SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, char* lds) {
-  constexpr int NPL = GemmCfg<BM, BN, X3>::NPL;
-  constexpr int A_TILE = GemmCfg<BM, BN, X3>::A_TILE, W_TILE = GemmCfg<BM, BN, X3>::W_TILE;
-  constexpr int STAGE = GemmCfg<BM, BN, X3>::STAGE;
+  constexpr int NPL = GemmCfg<BM, BN, X3, NS>::NPL;
+  constexpr int A_TILE = GemmCfg<BM, BN, X3, NS>::A_TILE, W_TILE = GemmCfg<BM, BN, X3, NS>::W_TILE;
+  constexpr int STAGE = GemmCfg<BM, BN, X3, NS>::STAGE;
+  constexpr int GLDS = GemmCfg<BM, BN, X3, NS>::GLDS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
 
   const int tid = threadIdx.x;
@@ -110,22 +129,36 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = g.K / BK;
+  unsigned offa[BM / 32], offw[BN / 32];
+  stage_offsets<BM>(offa, g.lda, m0, g.M - 1, wave, lane);
+  stage_offsets<BN>(offw, g.ldw, n0, g.N - 1, wave, lane);
   auto stage = [&](int kt, int buf) {
     char* s = lds + buf * STAGE;
-    stage_tile<BM>(a_hi, g.lda, m0, g.M - 1, kt * BK, s, wave, lane);
-    stage_tile<BN>(w_hi, g.ldw, n0, g.N - 1, kt * BK, s + A_TILE * NPL, wave, lane);
+    stage_tile<BM>(a_hi + kt * BK, offa, s, wave);
+    stage_tile<BN>(w_hi + kt * BK, offw, s + A_TILE * NPL, wave);
     if (X3) {
-      stage_tile<BM>(a_lo, g.lda, m0, g.M - 1, kt * BK, s + A_TILE, wave, lane);
-      stage_tile<BN>(w_lo, g.ldw, n0, g.N - 1, kt * BK, s + A_TILE * NPL + W_TILE, wave, lane);
+      stage_tile<BM>(a_lo + kt * BK, offa, s + A_TILE, wave);
+      stage_tile<BN>(w_lo + kt * BK, offw, s + A_TILE * NPL + W_TILE, wave);
     }
   };
 
-  stage(0, 0);
+  // NS LDS buffers, NS-1 k-tiles in flight.  Tile kt is retired by a COUNTED wait (the younger tiles stay in flight
+  // across the barrier), the barrier makes every wave's part of it visible, and the buffer read in the previous
+  // iteration is refilled right after the barrier.  With NS = 2 this is the classic double buffer (vmcnt(0)).
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nk) stage(s0, s0);
   const int fr = lane & 15, fq = lane >> 4;
+  int rbuf = 0, wbuf = NS - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();   // drains this wave's LDS-DMA (vmcnt(0)) and orders it for every wave
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* s = lds + (kt & 1) * STAGE;
+    const int ahead = nk - 1 - kt;                     // tiles issued after kt (capped at NS-2 by construction)
+    if (NS >= 4 && ahead >= 2) wait_dma_barrier<(NS >= 4 ? 2 : 0) * GLDS>();
+    else if (NS >= 3 && ahead >= 1) wait_dma_barrier<(NS >= 3 ? 1 : 0) * GLDS>();
+    else wait_dma_barrier<0>();
+    if (kt + NS - 1 < nk) stage(kt + NS - 1, wbuf);
+    wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
+    const char* s = lds + rbuf * STAGE;
+    rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
     const char* sa = s + wm * WM * ROW_BYTES;
     const char* sw = s + A_TILE * NPL + wn * WN * ROW_BYTES;
 #pragma unroll
@@ -238,11 +271,11 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 // workgroup walks tiles `blockIdx.x, blockIdx.x + gridDim.x, ...` of the flattened (batch entry, tile) space.  No tile
 // ever waits in the dispatcher's queue, so the small head kernels of the other stream are placed as soon as they
 // arrive instead of behind this kernel's not-yet-dispatched workgroups.
-template <int BM, int BN, bool X3>
+template <int BM, int BN, bool X3, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
-  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3>::LDS_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3, NS>::LDS_BYTES];
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
-    gemm_tile<BM, BN, X3>(g, w % tiles, w / tiles, lds);
+    gemm_tile<BM, BN, X3, NS>(g, w % tiles, w / tiles, lds);
     __syncthreads();     // the epilogue's LDS tile is dead before the next tile's first stage lands
   }
 }
@@ -250,15 +283,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g, 
 // Two independent problems in one launch (the layer-l GEMMs of Wav2Vec2 and of XLM-R have no dependence on each
 // other): the tiles of the small problem come first in the grid, so they start at once and ride along with the
 // large one instead of queueing, launch after launch, on a second stream behind it.
-template <int BM, int BN, bool X3>
+template <int BM, int BN, bool X3, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
                                                              const int tiles0, const int tiles1) {
-  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3>::LDS_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3, NS>::LDS_BYTES];
   // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches
   const bool first = (int)blockIdx.x < total0;
   const SerGemmArgs* g = first ? &g0 : &g1;
   const int w = first ? blockIdx.x : blockIdx.x - total0, tiles = first ? tiles0 : tiles1;
-  gemm_tile<BM, BN, X3>(*g, w % tiles, w / tiles, lds);
+  gemm_tile<BM, BN, X3, NS>(*g, w % tiles, w / tiles, lds);
 }
 
 // ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
@@ -274,6 +307,21 @@ extern "C" int ser_debug_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes; r
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
+// LDS stages for the bf16 (single-product) kernels, per tile shape: experiment knob, see ser_launch_gemm_bf16
+static int g_gemm_stages[4] = {2, 3, 2, 2};   // [0] 128x128  [1] 64x128  [2] 64x64  [3] 128x64
+// measured at BASELINE config 2 (ms/step): {2,2,2,2} 3.906, {2,3,2,2} 3.870, {2,4,2,2} 4.04, {3,3,2,2} 4.45 (96 KB of LDS
+// per 128x128 workgroup leaves one per CU): only the 64x128 tiles (~1.4 workgroups per CU, 48 k-tiles) gain from a
+// third buffer, and little: these GEMMs are bound by LDS traffic (DMA writes + fragment reads), not by DMA latency.
+extern "C" int ser_debug_set_gemm_stages(int s128, int s64x128, int s64, int s128x64) {
+  g_gemm_stages[0] = s128; g_gemm_stages[1] = s64x128; g_gemm_stages[2] = s64; g_gemm_stages[3] = s128x64;
+  return 0;
+}
+template <int BM, int BN>
+static int stages_for() {
+  const int v = g_gemm_stages[BM == 128 ? (BN == 128 ? 0 : 3) : (BN == 128 ? 1 : 2)];
+  return v < 2 ? 2 : (v > 4 ? 4 : v);
+}
+
 template <int BM, int BN>
 int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
@@ -287,10 +335,17 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
     rec.flops = 2.0 * g.M * (double)g.N * g.K * g.nb1 * g.nb2;   // algorithmic (one product per MAC)
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
-  if (g.a_lo && g.w_lo)
+  if (g.a_lo && g.w_lo) {
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
-  else
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+  } else {
+    const int ns = stages_for<BM, BN>();
+    if (ns == 3 && GemmCfg<BM, BN, false, 3>::LDS_BYTES <= 160 * 1024)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, 3>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    else if (ns == 4 && BM * BN <= 64 * 128)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    else
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+  }
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventRecord(rec.e1, st));
     g_prof.push_back(rec);
@@ -312,10 +367,17 @@ int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_
                 2.0 * big.M * (double)big.N * big.K * big.nb1 * big.nb2;
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
-  if (big.a_lo && big.w_lo)
+  if (big.a_lo && big.w_lo) {
     hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, true>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-  else
-    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+  } else {
+    const int ns = stages_for<BM, BN>();
+    if (ns == 3)
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, 3>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    else if (ns == 4 && BM * BN <= 64 * 128)
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    else
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+  }
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventRecord(rec.e1, st));
     g_prof.push_back(rec);

@@ -52,6 +52,32 @@ def test_gemm_bf16_nt(L, M, N, K, x3):
     assert (rec.cpu() - c.cpu()).abs().max().item() < (1e-4 if x3 else 4e-2)
 
 
+@pytest.mark.parametrize("stages", [3, 4])
+@pytest.mark.parametrize("M,N,K", [(199, 768, 768), (3184, 2304, 768), (300, 768, 3072), (257, 130, 192), (37, 200, 64),
+                                   (512, 768, 128)])
+def test_gemm_bf16_multi_stage_pipeline_is_bit_identical(L, M, N, K, stages):
+    """3- and 4-buffer LDS-DMA pipelines (counted vmcnt, raw barrier) against the double-buffered kernel: the
+    arithmetic is the same, only the staging schedule differs, so the results must be identical (a stale or early
+    read of a staged tile would show up here); K = 64 / 128 exercise the short-loop prologue and tail."""
+    a, w = _rand(M, K, seed=12), _rand(N, K, seed=13) / np.sqrt(K)
+    bias = _rand(N, seed=14)
+    ah, _ = L.split_bf16(a.cuda(), False)
+    wh, _ = L.split_bf16(w.cuda(), False)
+    outs = []
+    try:
+        for st in (2, stages):
+            L.lib.ser_debug_set_gemm_stages(st, st, st, st)
+            for _ in range(3):
+                c, _, _ = L.gemm_bf16_nt(ah, None, wh, None, bias.cuda(), L.ACT_NONE, None, out_f32=True, out_split=False)
+            torch.cuda.synchronize()
+            outs.append(c.clone())
+    finally:
+        L.lib.ser_debug_set_gemm_stages(2, 3, 2, 2)       # library default
+    assert torch.equal(outs[0], outs[1]), f"differs by {(outs[0] - outs[1]).abs().max().item()}"
+    ref = ah.cpu().double() @ wh.cpu().double().t() + bias.double()
+    assert (outs[1].cpu().double() - ref).abs().max().item() < 2e-5
+
+
 def test_gemm_strided_rows_is_conv(L):
     """Conv1d(k=3, stride=2) over channels-last activations as an NT GEMM with lda = stride*C."""
     C_, Lin, Cout, k, s = 64, 41, 64, 3, 2
