@@ -31,3 +31,22 @@ print("encoder graph alone  %.3f ms" % t(st.g_enc.replay))
 print("head graph alone     %.3f ms" % t(st.g_head.replay))
 print("adamw graph alone    %.3f ms" % t(st.g_opt.replay))
 print("pipelined step       %.3f ms" % t(lambda: st.step(*b)))
+
+# who finishes last inside an overlapped step?
+cur = torch.cuda.current_stream()
+acc_e = acc_h = 0.0
+N = 20
+for _ in range(N):
+    torch.cuda.synchronize()
+    e0, ee, eh = torch.cuda.Event(True), torch.cuda.Event(True), torch.cuda.Event(True)
+    e0.record(cur)
+    st.enc_stream.wait_stream(cur)
+    with torch.cuda.stream(st.enc_stream):
+        st.g_enc.replay()
+        ee.record(st.enc_stream)
+    st.g_head.replay()
+    st.g_opt.replay()
+    eh.record(cur)
+    torch.cuda.synchronize()
+    acc_e += e0.elapsed_time(ee); acc_h += e0.elapsed_time(eh)
+print("overlapped: encoder graph done at %.3f ms, head+adamw done at %.3f ms" % (acc_e / N, acc_h / N))
