@@ -190,6 +190,65 @@ class XlmrEngine:
         return out
 
 
+# ---- one-time tile tuning -----------------------------------------------------------------------------------------
+# At batch 16 an encoder GEMM is a few hundred tiles on 256 CUs, so its time is set by how the tile count divides
+# into the resident-workgroup slots; which tile height wins depends on the exact (rows, N, K).  The first eager
+# forward at a new batch geometry times the five heights on each of its GEMM shapes (~30 ms in total) and records
+# the winners in the library (ser_gemm_tile_hint).  The arithmetic of a tile does not depend on its height, so this
+# changes speed only.  Skipped during graph capture (the eager warm-up pass has already run it) and in bf16x3 mode.
+_TUNED = set()
+TILE_HEIGHTS = (64, 96, 128, 160, 192)
+
+
+def tune_gemm_shapes(shapes, device, reps=8):
+    """shapes: iterable of (rows_total, N, K) of bf16 NT GEMMs with N >= 128."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    for rows, N, K in shapes:
+        key = (int(rows), int(N), int(K), torch.device(device).index)
+        if key in _TUNED or N < 128 or rows <= 64:
+            continue
+        _TUNED.add(key)
+        a = torch.zeros(rows, K, dtype=torch.bfloat16, device=device)
+        w = torch.zeros(N, K, dtype=torch.bfloat16, device=device)
+        c = torch.empty(rows, N, dtype=torch.bfloat16, device=device)
+        best, best_ms = 0, float("inf")
+        try:
+            for bm in TILE_HEIGHTS:
+                L.lib.ser_debug_set_gemm_bm(bm)
+
+                def run():
+                    L.check(L.lib.ser_gemm_bf16_nt(a.data_ptr(), None, K, w.data_ptr(), None, K, rows, N, K, None, L.ACT_NONE, None,
+                                                   0, None, c.data_ptr(), None, N, L.stream_ptr()), "ser_gemm_bf16_nt")
+                run(); run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    run()
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if ms < best_ms:
+                    best, best_ms = bm, ms
+        finally:
+            L.lib.ser_debug_set_gemm_bm(0)
+        L.lib.ser_gemm_tile_hint(rows, N, K, best)
+
+
+def _w2v_gemm_shapes(cfg, B, T, extra_rows=0):
+    lens, t = [], T
+    for i in range(cfg.n_conv):
+        t = (t - cfg.conv_kernel[i]) // cfg.conv_stride[i] + 1
+        lens.append(t)
+    H, F = cfg.hidden, cfg.ffn
+    shapes = [(B * lens[i], cfg.conv_dim[i], cfg.conv_kernel[i] * cfg.conv_dim[i - 1]) for i in range(1, cfg.n_conv)]
+    rows = B * lens[-1]
+    shapes.append((rows, H, cfg.conv_dim[cfg.n_conv - 1]))
+    rows += extra_rows
+    shapes += [(rows, 3 * H, H), (rows, H, H), (rows, F, H), (rows, H, F)]
+    return shapes
+
+
 def forward_pair(audio_engine, text_engine, wave, ids, attn_mask):
     """Both frozen encoders in ONE call on the current stream (ser_encoders_forward): when the two models have the
     same depth their layers run in lock-step with one launch per step for both.  -> (a_enc [B,S_a,H], t_enc [B,S_t,H])."""
@@ -209,6 +268,8 @@ def forward_pair(audio_engine, text_engine, wave, ids, attn_mask):
     if na == 0 or nt == 0:
         L.check(-1, "ser_*_workspace_bytes")
     wsa, wst = a.ws.get(na, wave.device), t.ws.get(nt, ids.device)
+    if a.prec == L.PREC_BF16 and a.cfg.layers == t.cfg.layers and a.cfg.hidden == t.cfg.hidden:
+        tune_gemm_shapes(_w2v_gemm_shapes(a.cfg, B, T, extra_rows=Bt * St), wave.device)
     out_a = torch.empty(B, Sa, a.hidden, dtype=torch.float32, device=wave.device)
     out_t = torch.empty(Bt, St, t.hidden, dtype=torch.float32, device=ids.device)
     L.check(L.lib.ser_encoders_forward(C.byref(a.cfg), C.byref(a.w), wave.data_ptr(), B, T, C.byref(t.cfg), C.byref(t.w),

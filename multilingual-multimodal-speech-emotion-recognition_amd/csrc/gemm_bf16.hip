@@ -68,7 +68,7 @@ struct GemmCfg {
   static constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
   static constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
   static constexpr int STAGE = (A_TILE + W_TILE) * NPL;
-  static constexpr int EPI_BYTES = BM * (BN + 4) * 4;        // fp32 tile staged for the coalesced epilogue
+  static constexpr int EPI_BYTES = (BM / 2) * (BN + 4) * 4;  // fp32 HALF tile staged for the coalesced epilogue (two passes)
   static constexpr int LDS_RAW = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
   static constexpr int GLDS = (BM / 32 + BN / 32) * NPL;       // LDS-DMA instructions per stage per wave
   // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
@@ -187,19 +187,11 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     }
   }
 
-  // epilogue: accumulators -> LDS (row-major fp32 tile) -> coalesced 16-byte global stores.
+  // epilogue: accumulators -> LDS (row-major fp32 half tile) -> coalesced 16-byte global stores, in two passes: the
+  // rows of wave-row 0, then those of wave-row 1 (the staging area is half a tile, so tall tiles keep 2 workgroups per CU).
   // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
   constexpr int LDT = BN + 4;                       // floats; +4 keeps the two half-waves on different banks
-  __syncthreads();                                   // every wave is done reading the last k-tile
   float* tile = (float*)lds;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        tile[(wm * WM + i * 16 + fq * 4 + r) * LDT + wn * WN + j * 16 + fr] = acc[i][j][r];
-  __syncthreads();
   const long long coff = b1 * g.sc1 + b2 * g.sc2;
   const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
   const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
@@ -211,9 +203,21 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < g.N) ? bias[n + e] : 0.f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+  __syncthreads();                                   // k-loop reads (first pass) / previous pass's reads are done
+  if (wm == half) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(i * 16 + fq * 4 + r) * LDT + wn * WN + j * 16 + fr] = acc[i][j][r];
+  }
+  __syncthreads();
 #pragma unroll 2
-  for (int rr = tr; rr < BM; rr += RPI) {
-    const int m = m0 + rr;
+  for (int rr = tr; rr < WM; rr += RPI) {
+    const int m = m0 + half * WM + rr;
     if (m >= g.M || n >= g.N) continue;
     float v[8];
     const float4 t0 = *(const float4*)(tile + rr * LDT + tc), t1 = *(const float4*)(tile + rr * LDT + tc + 4);
@@ -238,16 +242,15 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
       }
       if (g.c_hi) {
         uint32_t ph[4], pl[4];
+        if (g.c_lo) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bf16_t h0, l0, h1, l1;
-          split_bf16(v[2 * e], h0, l0);
-          split_bf16(v[2 * e + 1], h1, l1);
-          ph[e] = h0 | ((uint32_t)h1 << 16);
-          pl[e] = l0 | ((uint32_t)l1 << 16);
+          for (int e = 0; e < 4; ++e) split_bf16x2(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+          *(uint4*)(g.c_lo + o) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ph[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
         }
         *(uint4*)(g.c_hi + o) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        if (g.c_lo) *(uint4*)(g.c_lo + o) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
       }
     } else {
 #pragma unroll
@@ -265,6 +268,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
       }
     }
   }
+  }   // half
 }
 
 // Persistent launch: the grid never exceeds what is resident at once (gridDim.x <= 2 workgroups per CU), each
@@ -318,6 +322,7 @@ extern "C" int ser_debug_set_gemm_stages(int s128, int s64x128, int s64, int s12
 }
 template <int BM, int BN>
 static int stages_for() {
+  if (BM != 64 && BM != 128) return 2;
   const int v = g_gemm_stages[BM == 128 ? (BN == 128 ? 0 : 3) : (BN == 128 ? 1 : 2)];
   return v < 2 ? 2 : (v > 4 ? 4 : v);
 }
@@ -336,13 +341,16 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
   if (g.a_lo && g.w_lo) {
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, true>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;     // parity mode keeps the two classic heights
+    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the 3-product mode", BM);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<XBM, BN, true>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
   } else {
     const int ns = stages_for<BM, BN>();
-    if (ns == 3 && GemmCfg<BM, BN, false, 3>::LDS_BYTES <= 160 * 1024)
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, 3>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
-    else if (ns == 4 && BM * BN <= 64 * 128)
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    constexpr bool MULTI = BM == 64 || BM == 128;      // only these shapes are built with more than two LDS buffers
+    if (MULTI && ns == 3)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (MULTI ? 3 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    else if (MULTI && ns == 4 && BM * BN <= 64 * 128)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (MULTI && BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
     else
       hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
   }
@@ -368,13 +376,16 @@ int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
   if (big.a_lo && big.w_lo) {
-    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, true>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;
+    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the 3-product mode", BM);
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<XBM, BN, true>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
   } else {
     const int ns = stages_for<BM, BN>();
-    if (ns == 3)
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, 3>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-    else if (ns == 4 && BM * BN <= 64 * 128)
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    constexpr bool MULTI = BM == 64 || BM == 128;
+    if (MULTI && ns == 3)
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (MULTI ? 3 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    else if (MULTI && ns == 4 && BM * BN <= 64 * 128)
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (MULTI && BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
     else
       hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
   }
@@ -397,6 +408,67 @@ static int gemm_check(const SerGemmArgs& g) {
 
 }  // namespace
 
+// Tile choice for BN = 128 in bf16 mode.  At these sizes (a few hundred tiles on 256 CUs) the time of a GEMM is
+// rounds x (time of one tile), rounds = ceil(tiles / resident workgroups): 522 tiles of 128 rows need two rounds of
+// 512 slots, 432 tiles of 160 rows need one.  Candidates: 64, 96, 128, 160, 192 rows; the cost of a tile grows with
+// its rows plus a constant (W panel, prologue, epilogue).  g_gemm_force_bm overrides (experiments / tests).
+static int g_gemm_force_bm = 0;
+extern "C" int ser_debug_set_gemm_bm(int bm) { g_gemm_force_bm = bm; return 0; }
+
+template <int BM>
+static int slots_per_cu() {
+  const int lds = GemmCfg<BM, 128, false, (BM == 64 ? 3 : 2)>::LDS_BYTES;
+  const int by_lds = (160 * 1024) / lds;
+  return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
+}
+// measured choices (ser_gemm_tile_hint, filled by the engines' one-time tuning pass) take precedence over the model
+struct TileHint { long long rows; int N, K, bm; };
+static std::vector<TileHint> g_tile_hints;
+extern "C" int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm) {
+  for (auto& h : g_tile_hints)
+    if (h.rows == rows_total && h.N == N && h.K == K) { h.bm = bm; return SER_OK; }
+  g_tile_hints.push_back(TileHint{rows_total, N, K, bm});
+  return SER_OK;
+}
+
+static int pick_bm(long long rows_a, long long rows_b, int N, int K, long long nb_b) {
+  if (g_gemm_force_bm) return g_gemm_force_bm;
+  for (const auto& h : g_tile_hints)
+    if (h.rows == rows_a + rows_b * nb_b && h.N == N && h.K == K && h.bm) return h.bm;
+  const int cands[5] = {64, 96, 128, 160, 192};
+  const int slots[5] = {slots_per_cu<64>(), slots_per_cu<96>(), slots_per_cu<128>(), slots_per_cu<160>(), slots_per_cu<192>()};
+  int best = 128;
+  double best_cost = 1e30;
+  for (int k = 0; k < 5; ++k) {
+    const int bm = cands[k];
+    const long long tiles = ((rows_a + bm - 1) / bm + ((rows_b + bm - 1) / bm) * nb_b) * ((N + 127) / 128);
+    const long long cap = 256LL * slots[k];
+    const long long rounds = (tiles + cap - 1) / cap;
+    const long long per_round = (tiles + rounds - 1) / rounds;
+    const long long per_cu = (per_round + 255) / 256;                     // resident tiles on the busiest CU
+    // fitted to scripts/gemm_bm_sweep.py: a tile costs (rows + ~100), a second tile on the same CU adds ~10 %,
+    // and a trailing partial round costs about 70 % of a full one
+    const double cost = (1.0 + 0.7 * (double)(rounds - 1)) * (0.9 + 0.1 * (double)per_cu) * (bm + 100.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = bm; }
+  }
+  return best;
+}
+
+template <int BM>
+static int launch_bm(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  return small ? launch_pair_cfg<BM, 128>(*small, big, st) : launch_cfg<BM, 128>(big, st);
+}
+static int launch_bn128(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  const long long rows_a = small ? (long long)small->M * small->nb1 * small->nb2 : 0;
+  switch (pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2)) {
+    case 64: return launch_bm<64>(small, big, st);
+    case 96: return launch_bm<96>(small, big, st);
+    case 160: return launch_bm<160>(small, big, st);
+    case 192: return launch_bm<192>(small, big, st);
+    default: return launch_bm<128>(small, big, st);
+  }
+}
+
 // `big` decides the tile shape; both problems must be in the same precision mode.
 int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) {
   SER_TRY(gemm_check(small));
@@ -408,6 +480,8 @@ int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, 
     SER_TRY(ser_launch_gemm_bf16(small, st));
     return ser_launch_gemm_bf16(big, st);
   }
+  const bool x3 = big.a_lo && big.w_lo;
+  if (!x3 && big.M > 64 && big.N >= 128) return launch_bn128(&small, big, st);
   if (t128 >= 384 && big.M > 64) return launch_pair_cfg<128, 128>(small, big, st);
   const long long t64 = (long long)ceil_div(big.M, 64) * ceil_div(big.N, 128) * nb;
   if (t64 >= 256 || big.M <= 64) return launch_pair_cfg<64, 128>(small, big, st);
@@ -415,16 +489,13 @@ int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, 
 }
 
 int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st) {
-  SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
-  SER_REQUIRE(g.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", g.K, BK);
-  SER_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm_bf16: lda=%d ldw=%d must be multiples of 8", g.lda, g.ldw);
-  SER_REQUIRE(g.a_hi && g.w_hi, "gemm_bf16: null operand");
-  SER_REQUIRE((g.a_lo == nullptr) == (g.w_lo == nullptr) || true, "unreachable");
-  SER_REQUIRE(g.nb1 >= 1 && g.nb2 >= 1, "gemm_bf16: bad batch");
+  SER_TRY(gemm_check(g));
   // tile choice: fill >= 256 CUs when the problem allows it
   const long long nb = (long long)g.nb1 * g.nb2;
   const long long t128 = (long long)ceil_div(g.M, 128) * ceil_div(g.N, 128) * nb;
   if (g.N <= 64) return launch_cfg<128, 64>(g, st);
+  const bool x3 = g.a_lo && g.w_lo;
+  if (!x3 && g.M > 64 && g.N >= 128 && t128 * 4 >= 256) return launch_bn128(nullptr, g, st);
   if (t128 >= 384 || g.M <= 64) {
     if (g.M <= 64) return launch_cfg<64, 128>(g, st);
     return launch_cfg<128, 128>(g, st);

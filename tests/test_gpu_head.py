@@ -238,9 +238,9 @@ def test_gate_feature_fusion_learnable_path(M):
 @pytest.mark.parametrize("rows,D,depth", [(16, 512, 35), (5, 512, 4), (16, 64, 3), (3, 128, 2), (1, 256, 1)])
 def test_classifier_persistent_stack_equals_per_block_launches(M, rows, D, depth):
     """The one-launch walk of the residual stack (csrc/persist.hip) against the launch-per-Linear path: same
-    arithmetic in the same order forward, so the logits must agree bit for bit; backward the LayerNorm expressions
-    are contracted differently by the compiler, so gradients agree to a few ulps per block (checked at 1e-4 relative
-    after 35 blocks); a second backward must accumulate; the hand-off waits must never have been abandoned."""
+    arithmetic, but the LayerNorm row sums are accumulated in a different order (operand layout + LDS reduction instead
+    of one wave per row), so logits and gradients agree to a few ulps per block (checked at 2e-5 / 1e-4 relative after
+    35 blocks); a second backward must accumulate; the hand-off waits must never have been abandoned."""
     from ser_amd import _ops as OP
     from ser_amd.models.classifier import AdvancedOpenMaxClassifier
     torch.manual_seed(rows * 1000 + D + depth)
@@ -269,10 +269,9 @@ def test_classifier_persistent_stack_equals_per_block_launches(M, rows, D, depth
     a, b = run(True), run(False)
     assert all(int(sc[1]) == 0 for sc in m._stack_cache[3]), "a hand-off wait was abandoned"
     assert all(int(sc[0]) >= 1 for sc in m._stack_cache[3]), "launch counters must advance"
-    if D == 512:      # same K split over the waves as the launch-per-Linear kernels
-        assert torch.equal(a[0], b[0]), f"logits differ by {(a[0] - b[0]).abs().max().item()}"
-    else:
-        np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # row statistics are summed in a different order than in the per-Linear kernels: agreement to a few ulps
+    np.testing.assert_allclose(a[0].cpu().numpy(), b[0].cpu().numpy(), rtol=2e-5, atol=2e-5)
+
     def same(u, v, what):
         scale = float(v.abs().max()) + 1e-12
         np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale, err_msg=what)

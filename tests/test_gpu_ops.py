@@ -78,6 +78,30 @@ def test_gemm_bf16_multi_stage_pipeline_is_bit_identical(L, M, N, K, stages):
     assert (outs[1].cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("bm", [64, 96, 160, 192])
+@pytest.mark.parametrize("M,N,K", [(3696, 2304, 768), (300, 768, 3072), (257, 130, 192), (97, 200, 64), (1000, 512, 1536)])
+def test_gemm_bf16_tile_heights_are_bit_identical(L, M, N, K, bm):
+    """Every tile height (chosen per shape by the tuning pass / cost model) computes each output element with the same
+    k order, so the results must equal those of the 128-row tiles exactly, including ragged last tiles and the
+    two-pass epilogue with bias + GELU + residual + bf16 planes."""
+    a, w = _rand(M, K, seed=22), _rand(N, K, seed=23) / np.sqrt(K)
+    bias, res = _rand(N, seed=24), _rand(M, N, seed=25)
+    ah, _ = L.split_bf16(a.cuda(), False)
+    wh, _ = L.split_bf16(w.cuda(), False)
+    outs = []
+    try:
+        for h in (128, bm):
+            L.lib.ser_debug_set_gemm_bm(h)
+            c, ch, _ = L.gemm_bf16_nt(ah, None, wh, None, bias.cuda(), L.ACT_GELU, res.cuda(), out_f32=True, out_split=True)
+            torch.cuda.synchronize()
+            outs.append((c.clone(), ch.clone()))
+    finally:
+        L.lib.ser_debug_set_gemm_bm(0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.functional.gelu(ah.cpu().double() @ wh.cpu().double().t() + bias.double()) + res.double()
+    assert (outs[1][0].cpu().double() - ref).abs().max().item() < 2e-5
+
+
 def test_gemm_strided_rows_is_conv(L):
     """Conv1d(k=3, stride=2) over channels-last activations as an NT GEMM with lda = stride*C."""
     C_, Lin, Cout, k, s = 64, 41, 64, 3, 2
