@@ -284,7 +284,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
             float4 o;
             o.x = (v[e].x - mean) * rstd * gm.x + bt.x; o.y = (v[e].y - mean) * rstd * gm.y + bt.y;
             o.z = (v[e].z - mean) * rstd * gm.z + bt.z; o.w = (v[e].w - mean) * rstd * gm.w + bt.w;
-            if (blockIdx.x == 0 && row < M)
+            if ((c >> 2) == (int)blockIdx.x && row < M)     // this workgroup's 16 columns of the dense copy
               *(float4*)((pass == 0 ? X1 : U) + blk * MD + (long long)row * D + c * 4) = o;
             if (pass == 1) *(float4*)(upan + row * PD + c * 4) = o;
             v[e] = o;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             d1[e].w = r2 * (dgv[e].w - a1 - xh[e].w * a2);
             const float4 ee = *(const float4*)(panel + row * PD + ch * 4);
             d1[e].x += ee.x; d1[e].y += ee.y; d1[e].z += ee.z; d1[e].w += ee.w;
-            if (blockIdx.x == 0) *(float4*)(DX1 + blk * MD + (long long)row * D + ch * 4) = d1[e];
+            if ((ch >> 2) == (int)blockIdx.x) *(float4*)(DX1 + blk * MD + (long long)row * D + ch * 4) = d1[e];
             const float4 zz = zh[k][e];
             const float4 gm = pg1[e];
             xh[e] = make_float4((zz.x - m1) * r1, (zz.y - m1) * r1, (zz.z - m1) * r1, (zz.w - m1) * r1);
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             o.z = r1 * (dgv[e].z - a1 - xh[e].z * a2);
             o.w = r1 * (dgv[e].w - a1 - xh[e].w * a2);
             *(float4*)(panel + row * PD + ch * 4) = o;
-            if (blockIdx.x == 0) *(float4*)(DH + blk * MD + (long long)row * D + ch * 4) = o;
+            if ((ch >> 2) == (int)blockIdx.x) *(float4*)(DH + blk * MD + (long long)row * D + ch * 4) = o;
           }
         }
       }
