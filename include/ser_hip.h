@@ -293,6 +293,10 @@ int ser_openmax(const float* feats, const float* act_vec, const float* walpha, c
  * hyper (device) = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; effective lr = hyper[0] * lr_mult. */
 int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float lr_mult,
               float weight_decay, float beta1, float beta2, float eps, void* stream);
+/* the same update for many flat segments (the ten optimizer groups of train.py:72-83 x their buckets) in one launch per
+ * 16 segments; ptrs = host array {p, g, m, v} per segment, n / lr_mult / weight_decay = host arrays per segment */
+int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay, int nseg,
+                    const float* hyper, float beta1, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

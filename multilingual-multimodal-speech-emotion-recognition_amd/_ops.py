@@ -369,6 +369,20 @@ def openmax_(feats, act_vec, walpha, wbeta, wtau, logits, thresh=0.3, reduce=0.8
     return logits
 
 
+def adamw_multi_(segments, hyper, b1, b2, eps):
+    """segments: list of (p, g, m, v, lr_mult, weight_decay) flat fp32 tensors -> one launch per 16 segments."""
+    import ctypes as C
+    n = len(segments)
+    ptrs = (C.c_void_p * (4 * n))()
+    cnt = (C.c_longlong * n)()
+    lrm = (C.c_float * n)()
+    wd = (C.c_float * n)()
+    for i, (p, g, m, v, lr_mult, weight_decay) in enumerate(segments):
+        ptrs[4 * i], ptrs[4 * i + 1], ptrs[4 * i + 2], ptrs[4 * i + 3] = L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v)
+        cnt[i], lrm[i], wd[i] = p.numel(), lr_mult, weight_decay
+    L.check(L.lib.ser_adamw_multi(ptrs, cnt, lrm, wd, n, L.ptr(hyper), b1, b2, eps, L.stream_ptr()), "ser_adamw_multi")
+
+
 def adamw_(p, g, m, v, hyper, lr_mult, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8):
     L.check(L.lib.ser_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper), lr_mult, weight_decay, beta1,
                             beta2, eps, L.stream_ptr()), "ser_adamw")

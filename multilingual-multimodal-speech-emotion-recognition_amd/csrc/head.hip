@@ -1053,6 +1053,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// the same update for up to 16 flat segments (one per optimizer group x bucket) in ONE launch: blockIdx.y = segment
+constexpr int ADAMW_MAX_SEG = 16;
+struct AdamwSeg {
+  float* p; const float* g; float* m; float* v;
+  long long n;
+  float lr_mult, wd;
+};
+struct AdamwBatch {
+  AdamwSeg s[ADAMW_MAX_SEG];
+};
+__global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch bt, const float* __restrict__ hyper, float b1,
+                                                          float b2, float eps) {
+  const AdamwSeg sg = bt.s[blockIdx.y];
+  const float lr = hyper[0] * sg.lr_mult, bc1 = hyper[1], bc2s = hyper[2];
+  const float step = lr / bc1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = sg.g[i];
+    float pi = sg.p[i] * (1.0f - lr * sg.wd);
+    const float mi = sg.m[i] + (gi - sg.m[i]) * (1.0f - b1);
+    const float vi = sg.v[i] * b2 + (1.0f - b2) * gi * gi;
+    const float den = sqrtf(vi) / bc2s + eps;
+    pi -= step * (mi / den);
+    sg.p[i] = pi; sg.m[i] = mi; sg.v[i] = vi;
+  }
+}
+
 static unsigned ew_blocks(long long n) {
   long long b = (n + 255) / 256;
   if (b > 2048) b = 2048;
@@ -1269,6 +1295,28 @@ extern "C" int ser_openmax(const float* feats, const float* act_vec, const float
   hipLaunchKernelGGL(openmax_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, feats, act_vec, walpha, wbeta,
                      wtau, B, C, F, thresh, reduce, logits);
   SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+// ptrs = host array {p, g, m, v} per segment, n = elements per segment, lr_mult / weight_decay per segment
+extern "C" int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay,
+                               int nseg, const float* hyper, float beta1, float beta2, float eps, void* stream) {
+  for (int s0 = 0; s0 < nseg; s0 += ADAMW_MAX_SEG) {
+    const int cnt = nseg - s0 < ADAMW_MAX_SEG ? nseg - s0 : ADAMW_MAX_SEG;
+    AdamwBatch bt;
+    memset(&bt, 0, sizeof(bt));
+    long long nmax = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const int k = s0 + i;
+      bt.s[i] = AdamwSeg{(float*)ptrs[4 * k], (const float*)ptrs[4 * k + 1], (float*)ptrs[4 * k + 2], (float*)ptrs[4 * k + 3],
+                         n[k], lr_mult[k], weight_decay[k]};
+      if (n[k] > nmax) nmax = n[k];
+    }
+    if (nmax <= 0) continue;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(ew_blocks(nmax), cnt), dim3(256), 0, (hipStream_t)stream, bt, hyper, beta1,
+                       beta2, eps);
+    SER_LAUNCH_CHECK();
+  }
   return SER_OK;
 }
 

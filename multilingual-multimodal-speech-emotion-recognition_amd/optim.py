@@ -75,18 +75,20 @@ class FlatAdamW:
         if self._plan is None:
             self._build_plan()
         b1, b2 = self.betas
+        segs_all = []                                   # (p, g, m, v, lr_mult, weight_decay) of every live segment
         for grp, segs, loose in self._plan:
             for b, s, e in segs:
                 if b.params[0].grad is None and all(p.grad is None for p in b.params):
                     continue
                 m, v = self._mv(id(b), b.flat)
-                O.adamw_(b.flat[s:e], b.gflat[s:e], m[s:e], v[s:e], self.hyper, grp["lr_mult"], grp["weight_decay"], b1, b2,
-                         self.eps)
+                segs_all.append((b.flat[s:e], b.gflat[s:e], m[s:e], v[s:e], grp["lr_mult"], grp["weight_decay"]))
             for p in loose:
                 if p.grad is None:
                     continue
                 m, v = self._mv(id(p), p.data)
-                O.adamw_(p.data, p.grad.contiguous(), m, v, self.hyper, grp["lr_mult"], grp["weight_decay"], b1, b2, self.eps)
+                segs_all.append((p.data, p.grad.contiguous(), m, v, grp["lr_mult"], grp["weight_decay"]))
+        if segs_all:
+            O.adamw_multi_(segs_all, self.hyper, b1, b2, self.eps)
 
     def step(self):
         dev = None

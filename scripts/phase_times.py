@@ -50,3 +50,13 @@ for _ in range(N):
     torch.cuda.synchronize()
     acc_e += e0.elapsed_time(ee); acc_h += e0.elapsed_time(eh)
 print("overlapped: encoder graph done at %.3f ms, head+adamw done at %.3f ms" % (acc_e / N, acc_h / N))
+
+# host cost of issuing one pipelined step (three graph launches + small copies), GPU idle at call time
+tt = 0.0
+for _ in range(20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.step(*b)
+    tt += time.perf_counter() - t0
+torch.cuda.synchronize()
+print("host time to issue one step: %.3f ms" % (tt / 20 * 1e3))
