@@ -194,7 +194,7 @@ def main():
             traffic = None
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
-                    kernel="gemm_bf16_nt_kernel", launches_per_step=n.value // nprof,
+                    kernel="gemm_bf16_nt_kernel + gemm_bf16_pair_kernel (same tile code; the pair form runs layer l of both encoders)", launches_per_step=n.value // nprof,
                     avg_launch_us=round(ms.value * 1e3 / max(1, n.value), 2),
                     algorithmic_gflop_per_step=round(fl.value / nprof / 1e9, 1),
                     mfma_products_per_mac=3 if args.precision == "bf16x3" else 1)
