@@ -102,6 +102,31 @@ def test_gemm_bf16_tile_heights_are_bit_identical(L, M, N, K, bm):
     assert (outs[1][0].cpu().double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("shapes", [((24, 384, 128), (140, 384, 128)), ((512, 768, 768), (3184, 768, 768)), ((65, 200, 128), (140, 200, 128)),
+                                    ((100, 384, 64), (140, 384, 64)), ((512, 2304, 768), (3184, 2304, 768))])
+def test_gemm_bf16_paired_launch_equals_single_launches(L, shapes):
+    """Two independent GEMMs in one launch (the layer-l products of the two encoders) against two single launches:
+    identical results, for tile shapes picked by the larger problem (incl. 64x64, where an earlier two-call-site
+    version of the kernel produced NaNs in the first problem)."""
+    import ctypes as C
+    f = L.lib.ser_debug_gemm_pair
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] * 2 + [C.c_void_p]
+    ops = []
+    for k, (M, N, K) in enumerate(shapes):
+        a, w = _rand(M, K, seed=30 + k), _rand(N, K, seed=40 + k) / np.sqrt(K)
+        ah, _ = L.split_bf16(a.cuda(), False)
+        wh, _ = L.split_bf16(w.cuda(), False)
+        ops.append((ah, wh, torch.full((M, N), float("nan"), device="cuda"), M, N, K))
+    (a0, w0, c0, M0, N0, K0), (a1, w1, c1, M1, N1, K1) = ops
+    L.check(f(a0.data_ptr(), w0.data_ptr(), M0, N0, K0, c0.data_ptr(), a1.data_ptr(), w1.data_ptr(), M1, N1, K1, c1.data_ptr(),
+              L.stream_ptr()), "ser_debug_gemm_pair")
+    torch.cuda.synchronize()
+    for ah, wh, c, M, N, K in ops:
+        single, _, _ = L.gemm_bf16_nt(ah, None, wh, None, None, L.ACT_NONE, None, out_f32=True, out_split=False)
+        assert torch.equal(c, single), f"{(M, N, K)}: differs by {(c - single).abs().max().item()}"
+
+
 def test_gemm_strided_rows_is_conv(L):
     """Conv1d(k=3, stride=2) over channels-last activations as an NT GEMM with lda = stride*C."""
     C_, Lin, Cout, k, s = 64, 41, 64, 3, 2
