@@ -298,6 +298,17 @@ int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const f
 int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay, int nseg,
                     const float* hyper, float beta1, float beta2, float eps, void* stream);
 
+/* ---- data feed on the device (src/data/preprocess.py:50-73) ---------------------------
+ * ser_resample: torchaudio.functional.resample (windowed sinc, Hann window, lowpass_filter_width 6, rolloff 0.99 by
+ * default) of x[B, T] into y[B, ser_resample_out_len(T, orig, new)]; speed_perturb is the 16000 -> int(16000 f) ->
+ * 16000 round trip of it.  ser_add_noise_snr: y = clamp(x + N(0, mean(x^2) / 10^(snr/10)), -1, 1) per clip, noise from
+ * a counter-based generator keyed by (seed, clip, sample); sigma = device scratch [B]. */
+int ser_resample_out_len(int T, int orig_freq, int new_freq);
+int ser_resample(const float* x, int B, int T, int orig_freq, int new_freq, int lowpass_filter_width, float rolloff, float* y,
+                 void* stream);
+int ser_add_noise_snr(const float* x, int B, int T, const float* snr_db, unsigned long long seed, float* sigma, float* y,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

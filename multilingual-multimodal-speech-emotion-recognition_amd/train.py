@@ -72,6 +72,26 @@ def augment(audio_list):
     return out
 
 
+def augment_device(wave, seed):
+    """The same augmentation policy (ref train.py:129-142, host RNG draws in the same order) for an equal-length batch
+    already on the device: resampling and noise run in HIP (data/gpu_augment.py)."""
+    from ser_amd.data import gpu_augment as G
+    rows, noisy, snrs = [], [], []
+    for b in range(wave.shape[0]):
+        w = wave[b:b + 1]
+        if torch.rand(1).item() < 0.5:
+            w = G.speed_perturb(w, 0.9 + 0.2 * torch.rand(1).item())
+        if torch.rand(1).item() < 0.5:
+            noisy.append(b)
+            snrs.append(10 + 10 * torch.rand(1).item())
+        rows.append(w)
+    out = torch.cat(rows, dim=0)
+    if noisy:
+        idx = torch.tensor(noisy, device=wave.device)
+        out[idx] = G.add_noise_snr(out[idx], torch.tensor(snrs), seed)
+    return out
+
+
 def tokenise(te, text_list, device):
     enc = te.tokenizer(text_list, padding=True, truncation=True, return_tensors="pt")
     return enc["input_ids"].to(device), enc["attention_mask"].to(device)
@@ -121,12 +141,14 @@ def main(argv=None):
         for bi, (audio_list, text_list, labels) in enumerate(train_loader):
             if bi % world != rank:
                 continue
-            if args.augment:
-                audio_list = augment(audio_list)
             lens = {w.numel() for w in audio_list}
+            if args.augment and len(lens) != 1:
+                audio_list = augment(audio_list)
             ids, mask = tokenise(te, text_list, device)
             if len(lens) == 1:
                 wave = torch.stack(audio_list).to(device)
+                if args.augment:
+                    wave = augment_device(wave, seed=epoch * 1000003 + bi)
                 loss = stepper.step(wave, ids, mask, labels.to(device))
             else:   # ragged clips: the reference's pad-to-longest semantics, eager launches
                 opt.zero_grad(set_to_none=True)
