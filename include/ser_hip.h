@@ -155,6 +155,20 @@ int ser_xlmr_forward(const SerXlmrConfig* cfg, const SerXlmrWeights* w, const in
                      const float* attn_mask, int B, int S, int prec, float* out, void* workspace,
                      size_t workspace_bytes, void* stream);
 
+/* Front-end stages on their own (the whole-model entries above call the same launchers):
+ * conv0 + GroupNorm + erf-GELU on raw clips, clip normalisation included (hf feature_extraction_wav2vec2.py:78-96 +
+ * modeling_wav2vec2.py:302-323) -> channels-last bf16 planes [B, L0, C0], L0 = (T - KW) / ST + 1 (y_lo may be NULL);
+ * the zero-padded (clip, group) slab the positional conv GEMM reads (modeling_wav2vec2.py:326-368);
+ * XLM-R embeddings: position ids + word/type/position gather + LayerNorm (modeling_xlm_roberta.py:75-121,142-155),
+ * pos_scratch = B * S ints. */
+size_t ser_conv0_workspace_bytes(int B, int L0, int C0);
+int ser_conv0_gn_gelu(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0, int KW,
+                      int ST, uint16_t* y_hi, uint16_t* y_lo, void* workspace, size_t workspace_bytes, void* stream);
+int ser_posconv_slab(const float* z, int B, int S, int H, int G, int K, uint16_t* slab_hi, uint16_t* slab_lo, void* stream);
+int ser_xlmr_embed(const int64_t* ids, int B, int S, const float* word_emb, const float* pos_emb, const float* type_emb,
+                   const float* gamma, const float* beta, float eps, int D, int vocab, int max_pos, int pad_id,
+                   int* pos_scratch, float* y, uint16_t* y_hi, uint16_t* y_lo, void* stream);
+
 /* Both frozen encoders in one call on one stream (audio_encoder.py:110 + text_encoder.py:55 of the same batch).
  * With equal depth (Base 12 + 12) the transformer layers of the two models run in lock-step, ONE launch per step
  * for both (grouped GEMM / attention / LayerNorm), instead of ~90 small XLM-R launches queueing behind the

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void xlmr_embed_kernel(const int64_t* __restri
       bf16_t h[4], l[4];
       split_bf16(o.x, h[0], l[0]); split_bf16(o.y, h[1], l[1]);
       split_bf16(o.z, h[2], l[2]); split_bf16(o.w, h[3], l[3]);
-      *(uint2*)(yhi + off) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+      if (yhi) *(uint2*)(yhi + off) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
       if (ylo) *(uint2*)(ylo + off) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
     }
   }
@@ -635,4 +635,31 @@ int ser_launch_xlmr_embed(const int64_t* ids, int B, int S, const float* wemb, c
 #undef EMB
   SER_LAUNCH_CHECK();
   return SER_OK;
+}
+
+// ---- C-ABI entries for the front-end stages (one per kernel group K2 / K5 / K7 of SURVEY section 2.2) -------------
+extern "C" size_t ser_conv0_workspace_bytes(int B, int L0, int C0) { return ser_conv0_scratch_bytes(B, L0, C0); }
+
+extern "C" int ser_conv0_gn_gelu(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0,
+                                 int KW, int ST, uint16_t* y_hi, uint16_t* y_lo, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  SER_REQUIRE(wave && w && gn_g && gn_b && y_hi && workspace && B > 0 && T >= KW, "conv0: bad arguments");
+  const int L0 = (T - KW) / ST + 1;
+  SER_REQUIRE(workspace_bytes >= ser_conv0_scratch_bytes(B, L0, C0), "conv0: workspace too small");
+  return ser_launch_conv0(wave, B, T, w, gn_g, gn_b, C0, KW, ST, L0, y_hi, y_lo, workspace, (hipStream_t)stream);
+}
+
+extern "C" int ser_posconv_slab(const float* z, int B, int S, int H, int G, int K, uint16_t* slab_hi, uint16_t* slab_lo,
+                                void* stream) {
+  SER_REQUIRE(z && slab_hi && B > 0 && S > 0 && G > 0 && H % G == 0, "posconv_slab: bad arguments");
+  return ser_launch_posconv_slab(z, B, S, H, G, K, slab_hi, slab_lo, (hipStream_t)stream);
+}
+
+extern "C" int ser_xlmr_embed(const int64_t* ids, int B, int S, const float* word_emb, const float* pos_emb,
+                              const float* type_emb, const float* gamma, const float* beta, float eps, int D, int vocab,
+                              int max_pos, int pad_id, int* pos_scratch, float* y, uint16_t* y_hi, uint16_t* y_lo, void* stream) {
+  SER_REQUIRE(ids && word_emb && pos_emb && type_emb && gamma && beta && pos_scratch && y && B > 0 && S > 0,
+              "xlmr_embed: bad arguments");
+  return ser_launch_xlmr_embed(ids, B, S, word_emb, pos_emb, type_emb, gamma, beta, eps, D, vocab, max_pos, pad_id, pos_scratch,
+                               y, y_hi, y_lo, (hipStream_t)stream);
 }

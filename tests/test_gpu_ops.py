@@ -172,3 +172,64 @@ def test_self_attention(L, B, S, heads, masked, x3):
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H)
     err = (got.double() - ref).abs().max().item()
     assert err < (5e-5 if x3 else 2e-2), f"max abs err {err}"
+
+
+def test_conv0_groupnorm_gelu_entry_against_torch(L):
+    """K2 on its own through the C ABI: clip normalisation + Conv1d(1->C, k10, s5) + GroupNorm(C groups) + erf-GELU,
+    with a DC offset and a ragged last chunk, against torch in float64."""
+    import ctypes as C
+    B, T, C0, KW, ST = 3, 3001, 64, 10, 5
+    g = torch.Generator().manual_seed(5)
+    wave = 0.1 * torch.randn(B, T, generator=g) + 0.25
+    w = torch.randn(C0, KW, generator=g) * 0.3
+    gn_g, gn_b = 1 + 0.1 * torch.randn(C0, generator=g), 0.1 * torch.randn(C0, generator=g)
+    L0 = (T - KW) // ST + 1
+    lib = L.lib
+    lib.ser_conv0_workspace_bytes.restype = C.c_size_t
+    lib.ser_conv0_workspace_bytes.argtypes = [C.c_int] * 3
+    lib.ser_conv0_gn_gelu.restype = C.c_int
+    lib.ser_conv0_gn_gelu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    nb = lib.ser_conv0_workspace_bytes(B, L0, C0)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    hi = torch.empty(B, L0, C0, dtype=torch.bfloat16, device="cuda")
+    lo = torch.empty_like(hi)
+    d = [t_.cuda() for t_ in (wave, w, gn_g, gn_b)]
+    L.check(lib.ser_conv0_gn_gelu(d[0].data_ptr(), B, T, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), C0, KW, ST,
+                                  hi.data_ptr(), lo.data_ptr(), ws.data_ptr(), nb, L.stream_ptr()), "ser_conv0_gn_gelu")
+    torch.cuda.synchronize()
+    x = wave.double()
+    x = (x - x.mean(1, keepdim=True)) / torch.sqrt(x.var(1, unbiased=False, keepdim=True) + 1e-7)
+    y = torch.nn.functional.conv1d(x[:, None], w.double()[:, None], stride=ST)
+    y = torch.nn.functional.group_norm(y, C0, gn_g.double(), gn_b.double(), eps=1e-5)
+    ref = torch.nn.functional.gelu(y).transpose(1, 2)
+    got = hi.float().cpu().double() + lo.float().cpu().double()
+    assert (got - ref).abs().max().item() < 3e-5
+
+
+def test_xlmr_embed_entry_against_torch(L):
+    """K7 on its own: position ids from the non-pad cumsum, word + type + position gather, LayerNorm."""
+    import ctypes as C
+    B, S, D, V, P, pad = 3, 9, 128, 50, 40, 1
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(2, V, (B, S), generator=g)
+    ids[0, -3:] = pad
+    ids[2, -1] = pad
+    we, pe, te = torch.randn(V, D, generator=g), torch.randn(P, D, generator=g), torch.randn(1, D, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    lib = L.lib
+    lib.ser_xlmr_embed.restype = C.c_int
+    lib.ser_xlmr_embed.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, C.c_int] + \
+                                  [C.c_void_p] * 5
+    d = [t_.cuda() for t_ in (ids, we, pe, te, gam, bet)]
+    pos = torch.empty(B * S, dtype=torch.int32, device="cuda")
+    y = torch.empty(B * S, D, device="cuda")
+    L.check(lib.ser_xlmr_embed(d[0].data_ptr(), B, S, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                               d[5].data_ptr(), 1e-5, D, V, P, pad, pos.data_ptr(), y.data_ptr(), None, None, L.stream_ptr()),
+            "ser_xlmr_embed")
+    torch.cuda.synchronize()
+    m = (ids != pad).long()
+    pid = torch.cumsum(m, 1) * m + pad
+    ref = torch.nn.functional.layer_norm((we[ids] + pe[pid] + te[0]).double(), (D,), gam.double(), bet.double(), 1e-5)
+    assert torch.equal(pos.cpu().view(B, S).long(), pid)
+    assert (y.cpu().double().view(B, S, D) - ref).abs().max().item() < 1e-5
