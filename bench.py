@@ -9,6 +9,7 @@ adapters + cross-attention + pooling + fusion + 35-block classifier trained.
 Prints ONE JSON line (rank 0).  `value` = utterances/s over all ranks, inputs resident in HBM.
 """
 import argparse
+import math
 import ctypes as C
 import json
 import os
@@ -172,6 +173,13 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * args.steps / elapsed
     loss = float(stepper.loss.item())
+    # fail loudly (outside the timed region) if a step went wrong: a non-finite loss, or a persistent-kernel wait that
+    # was abandoned (sticky word 1 of the classifier stack's scratch areas, csrc/persist.hip)
+    if not math.isfinite(loss):
+        raise RuntimeError(f"non-finite loss after the timed steps: {loss}")
+    cache = getattr(sysm.classifier, "_stack_cache", None)
+    if cache is not None and any(int(sc[1]) != 0 for sc in cache[3]):
+        raise RuntimeError("a hand-off wait inside the persistent classifier kernels was abandoned")
 
     # ---- roofline leg: HIP events around every launch of the dominant kernel (the encoder MFMA GEMM) -------
     roof = None
