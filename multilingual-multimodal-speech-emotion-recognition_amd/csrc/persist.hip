@@ -206,6 +206,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
   const int i = lane & 15, q = lane >> 4;
   const int n0 = blockIdx.x * 16, n = n0 + i;
   const int nch4 = D >> 2, nchunk = D >> 4, PD = D + PPAD;
+  const float invD = 1.0f / (float)D;            // exact for the power-of-two widths in use
   float* panel = lds_dyn;                             // [16][PD]  block input h, then a
   float* upan = lds_dyn + 16 * PD;                    // [16][PD]  u = LN(LN(h))
   const int nit = (nchunk - w + SW - 1) / SW;          // <= 4 (D <= 512)
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
       }
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
-        const float mean = wave_sum(s) / (float)D;
+        const float mean = wave_sum(s) * invD;
         float qq = 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e)
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
             const float a_ = v[e].x - mean, bb = v[e].y - mean, c2 = v[e].z - mean, d = v[e].w - mean;
             qq += (a_ * a_ + bb * bb) + (c2 * c2 + d * d);
           }
-        const float rstd = 1.0f / sqrtf(wave_sum(qq) / (float)D + eps);
+        const float rstd = rsqrtf(wave_sum(qq) * invD + eps);      // v_rsq_f32 (1 ulp) instead of IEEE sqrt + divide
         if (lane == 0) { st[row][2 * pass] = mean; st[row][2 * pass + 1] = rstd; }
         s = 0.f;
 #pragma unroll
@@ -398,6 +399,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
                                                             int D, void* scratch) {
   extern __shared__ float lds_dyn[];
   const int PD = D + PPAD;
+  const float invD = 1.0f / (float)D;
   float* panel = lds_dyn;                             // [16][PD]  gradient at the current block's output
   float* xpan = lds_dyn + 16 * PD;                    // [16][PD]  da, then du, as they arrive
   __shared__ float red[SW][64][4];
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             s2 += (dgv[e].x * xh[e].x + dgv[e].y * xh[e].y) + (dgv[e].z * xh[e].z + dgv[e].w * xh[e].w);
           }
         }
-        float a1 = wave_sum(s1) / (float)D, a2 = wave_sum(s2) / (float)D;
+        float a1 = wave_sum(s1) * invD, a2 = wave_sum(s2) * invD;
         s1 = 0.f; s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             s2 += (dgv[e].x * xh[e].x + dgv[e].y * xh[e].y) + (dgv[e].z * xh[e].z + dgv[e].w * xh[e].w);
           }
         }
-        a1 = wave_sum(s1) / (float)D; a2 = wave_sum(s2) / (float)D;
+        a1 = wave_sum(s1) * invD; a2 = wave_sum(s2) * invD;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int ch = lane + 64 * e;
