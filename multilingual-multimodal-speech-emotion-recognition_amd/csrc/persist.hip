@@ -127,6 +127,8 @@ struct StackBlockPtrs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long ull;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int SW = 8;            // waves per workgroup
 constexpr int PPAD = 4;          // LDS panel row padding (floats): rows land on different banks
@@ -402,6 +404,9 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
   const float invD = 1.0f / (float)D;
   float* panel = lds_dyn;                             // [16][PD]  gradient at the current block's output
   float* xpan = lds_dyn + 16 * PD;                    // [16][PD]  da, then du, as they arrive
+  float* x1pan = lds_dyn + 2 * 16 * PD;               // [16][D]   x1 of the current block   } filled by LDS-DMA at the top of
+  float* hpan = x1pan + 16 * D;                       // [16][D]   input of the current block } the block: no registers held
+  float* gpan = hpan + 16 * D;                        // [2][D]    gamma of LN1, LN2
   __shared__ float red[SW][64][4];
   const StackScratch sc = stack_scratch(scratch);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -414,6 +419,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
   const int ri = min(i, M - 1);
   const unsigned tagbase = (*sc.launch + 1u) << 12;
   const long long slot_elems = (long long)16 * D;
+  unsigned long long* dbg = g_stack_dbg ? g_stack_dbg + 8 * 64 : nullptr;     // second half of the timeline buffer
   for (int idx = threadIdx.x; idx < M * nch4; idx += SW * 64) {
     const float4 v = ((const float4*)(DH + (long long)L * MD))[idx];
     *(float4*)(panel + (idx / nch4) * PD + (idx % nch4) * 4) = v;
@@ -435,30 +441,30 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
     for (int u = 0; u < 16; ++u) bw2[u] = P.W1[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
     const float* hin = blk == 0 ? x0 : Hs + (long long)(blk - 1) * MD;
     const float* stp = ST + (long long)blk * 4 * M;
-    float4 zx1[2][2], zh[2][2];
     float sm[2][4];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int row = min(w + SW * k, M - 1);
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4) sm[k][t4] = stp[t4 * M + row];
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int ch = min(lane + 64 * e, nch4 - 1);
-        zx1[k][e] = *(const float4*)(X1 + blk * MD + (long long)row * D + ch * 4);
-        zh[k][e] = *(const float4*)(hin + (long long)row * D + ch * 4);
-      }
     }
-    float4 pg1[2], pg2[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int ch = min(lane + 64 * e, nch4 - 1);
-      pg1[e] = *(const float4*)(P.g1 + ch * 4);
-      pg2[e] = *(const float4*)(P.g2 + ch * 4);
+    // saved activations of this block -> LDS, asynchronously (needed after the second hand-off; the LDS-DMA queue is
+    // in order, so they have landed when the tagged loads issued later return, and the barrier inside ll_fetch_panel
+    // publishes them to every wave).  The previous block's LayerNorm backward finished with a workgroup barrier.
+    for (int idx = threadIdx.x; idx < 16 * nch4; idx += SW * 64) {      // uniform trip count: 16 nch4 is a multiple of 64
+      const int row = min(idx / nch4, M - 1), ch = idx % nch4;
+      const int slot64 = (idx & ~63) * 16;                               // wave-uniform LDS base, lane-linear 16-byte slots
+      __builtin_amdgcn_global_load_lds((gptr_t)(X1 + blk * MD + (long long)row * D + ch * 4), (lptr_t)((char*)x1pan + slot64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(hin + (long long)row * D + ch * 4), (lptr_t)((char*)hpan + slot64), 16, 0, 0);
+    }
+    for (int idx = threadIdx.x; idx < 2 * nch4; idx += SW * 64) {        // the two gamma vectors, same route
+      const float* src = idx < nch4 ? P.g1 + idx * 4 : P.g2 + (idx - nch4) * 4;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)((char*)gpan + (idx & ~63) * 16), 16, 0, 0);
     }
     float amask[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) amask[r] = A[blk * MD + (long long)min(q * 4 + r, M - 1) * D + c];
+    STACK_MARK(0);
     // ---- da = (dh' W2) * relu'(a)
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -472,6 +478,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
       for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
     }
     lds_barrier();
+    STACK_MARK(1);
     if (w == 0) {
       ull* slot = sc.ring + (p1 & 1) * slot_elems;
 #pragma unroll
@@ -491,8 +498,10 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
 #pragma unroll
       for (int u = 0; u < 16; ++u) bw[u] = Wp[(long long)min((w + u * SW) * 4 + q, D - 1) * D + c];
     }
+    STACK_MARK(2);
     // ---- du = da W1
     if (!ll_fetch_panel(sc.ring + (p1 & 1) * slot_elems, xpan, M, D, tagbase + p1 + 1, sc.abort)) return;
+    STACK_MARK(3);
     {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -505,6 +514,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
       for (int r = 0; r < 4; ++r) red[w][lane][r] = acc[r];
     }
     lds_barrier();
+    STACK_MARK(4);
     if (w == 0) {
       ull* slot = sc.ring + (p2 & 1) * slot_elems;
 #pragma unroll
@@ -519,7 +529,9 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
       }
     }
     // ---- panel <- LN1'(panel + LN2'(du)), rows w, w + 8
+    STACK_MARK(5);
     if (!ll_fetch_panel(sc.ring + (p2 & 1) * slot_elems, xpan, M, D, tagbase + p2 + 1, sc.abort)) return;
+    STACK_MARK(6);
     {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -532,9 +544,9 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
         for (int e = 0; e < 2; ++e) {
           const int ch = lane + 64 * e;
           if (ch < nch4) {
-            const float4 zz = zx1[k][e];
+            const float4 zz = *(const float4*)(x1pan + row * D + ch * 4);
             const float4 d = *(const float4*)(xpan + row * PD + ch * 4);
-            const float4 gm = pg2[e];
+            const float4 gm = *(const float4*)(gpan + D + ch * 4);
             xh[e] = make_float4((zz.x - m2) * r2, (zz.y - m2) * r2, (zz.z - m2) * r2, (zz.w - m2) * r2);
             dgv[e] = make_float4(d.x * gm.x, d.y * gm.y, d.z * gm.z, d.w * gm.w);
             s1 += (dgv[e].x + dgv[e].y) + (dgv[e].z + dgv[e].w);
@@ -554,8 +566,8 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             const float4 ee = *(const float4*)(panel + row * PD + ch * 4);
             d1[e].x += ee.x; d1[e].y += ee.y; d1[e].z += ee.z; d1[e].w += ee.w;
             if ((ch >> 2) == (int)blockIdx.x) *(float4*)(DX1 + blk * MD + (long long)row * D + ch * 4) = d1[e];
-            const float4 zz = zh[k][e];
-            const float4 gm = pg1[e];
+            const float4 zz = *(const float4*)(hpan + row * D + ch * 4);
+            const float4 gm = *(const float4*)(gpan + ch * 4);
             xh[e] = make_float4((zz.x - m1) * r1, (zz.y - m1) * r1, (zz.z - m1) * r1, (zz.w - m1) * r1);
             dgv[e] = make_float4(d1[e].x * gm.x, d1[e].y * gm.y, d1[e].z * gm.z, d1[e].w * gm.w);
             s1 += (dgv[e].x + dgv[e].y) + (dgv[e].z + dgv[e].w);
@@ -578,6 +590,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
         }
       }
     }
+    STACK_MARK(7);
     lds_barrier();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *sc.launch = *sc.launch + 1u;
@@ -665,7 +678,7 @@ extern "C" int ser_stack_bwd(const void* ptr_table, const float* x0, const float
                              void* stream) {
   SER_TRY(stack_check(L, M, D));
   SER_REQUIRE(scratch != nullptr && ((uintptr_t)scratch & 255) == 0, "classifier stack: scratch must be 256-byte aligned");
-  hipLaunchKernelGGL(stack_bwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)2 * 16 * (D + PPAD) * sizeof(float),
+  hipLaunchKernelGGL(stack_bwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)(2 * 16 * (D + PPAD) + 2 * 16 * D + 2 * D) * sizeof(float),
                      (hipStream_t)stream, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, A, ST, DH, DA, DU, DX1, L, M, D,
                      scratch);
   SER_LAUNCH_CHECK();

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 Lb = 35
 m = AdvancedOpenMaxClassifier(input_dim=512, num_labels=4, num_layers=Lb, base_dim=512).to(dev).train()
 x = torch.randn(16, 512, device=dev, requires_grad=True)
-buf = torch.zeros(Lb * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(2 * 8 * 64, dtype=torch.int64, device=dev)     # [fwd | bwd][block][8 marks], up to 64 blocks each
 for it in range(3):
     if it == 2:
         L.lib.ser_debug_stack_timeline.argtypes = [C.c_void_p]
@@ -20,7 +20,7 @@ for it in range(3):
     (logits.sum() + unc.sum()).backward()
     torch.cuda.synchronize()
 L.lib.ser_debug_stack_timeline(None)
-t = buf.cpu().view(Lb, 8).double() * 0.01          # us (100 MHz clock)
+t = buf.cpu()[:Lb * 8].view(Lb, 8).double() * 0.01          # us (100 MHz clock)
 names = ["fetch h", "LN stats", "MFMA A + reduce", "finalize A (stores)", "fetch a", "MFMA B + reduce", "finalize B"]
 d = t[1:, 1:] - t[1:, :-1]
 for k, nme in enumerate(names):
@@ -28,6 +28,14 @@ for k, nme in enumerate(names):
 nxt = t[2:, 0] - t[1:-1, 7]
 print(f"{'to next block':22s} {nxt.mean():6.2f} us")
 print(f"per block {(t[2:, 0] - t[1:-1, 0]).mean():.2f} us")
+tb = buf.cpu()[8 * 64:8 * 64 + Lb * 8].view(Lb, 8).double() * 0.01      # backward: blocks run L-1 .. 0
+names_b = ["MFMA da + reduce", "finalize da", "fetch da", "MFMA du + reduce", "finalize du", "fetch du", "LayerNorm backward"]
+db = tb[1:-1, 1:] - tb[1:-1, :-1]
+print("backward:")
+for k, nme in enumerate(names_b):
+    print(f"  {nme:20s} {db[:, k].mean():6.2f} us  (min {db[:, k].min():.2f} max {db[:, k].max():.2f})")
+print(f"  to next block        {(tb[:-2, 0] - tb[1:-1, 7]).mean():6.2f} us")
+print(f"  per block {(tb[:-2, 0] - tb[1:-1, 0]).mean():.2f} us")
 
 # plain kernel durations without the timestamps (events around back-to-back launches)
 from ser_amd import _ops as O
