@@ -232,6 +232,11 @@ int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const
                   void* stream);
 int ser_stack_ln_param_bwd(const void* grad_table, const float* x0, const float* Hs, const float* X1, const float* ST,
                            const float* DU, const float* DX1, int L, int M, int D, int accumulate, void* stream);
+/* Precision of the BACKWARD token-level (M > 16) head products (ser_linear_dgrad, ser_linear_wgrad*): 3 MFMA products
+ * per multiply (hi*hi + lo*hi + hi*lo, fp32-equivalent; default) or 1 (operands rounded to bf16, fp32 accumulation -
+ * what mixed-precision training does for every matmul).  Forward products always use 3.  Process-wide setting. */
+int ser_set_head_backward_products(int n);
+int ser_get_head_backward_products(void);
 /* relu_mask (may be NULL): the ReLU OUTPUT of the layer that produced x; when given, dx is multiplied by
  * relu'(mask), i.e. the activation backward is fused into the dgrad epilogue. */
 int ser_linear_dgrad(const float* dy, const float* W, const float* relu_mask, float* dx, int M, int N, int K,

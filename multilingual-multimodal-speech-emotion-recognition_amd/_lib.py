@@ -166,6 +166,8 @@ _sig("ser_linear_wgrad_group", i32, C.POINTER(vp), C.POINTER(i32), i32, i32, vp,
 _sig("ser_linear_wgrad_batch", i32, C.POINTER(vp), C.POINTER(i32), i32, i32, i32, vp)
 _sig("ser_linear_fwd_ln2", i32, vp, vp, vp, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, vp)
 _sig("ser_linear_dgrad", i32, vp, vp, vp, vp, i32, i32, i32, i32, vp)
+_sig("ser_set_head_backward_products", i32, i32)
+_sig("ser_get_head_backward_products", i32)
 _sig("ser_resample_out_len", i32, i32, i32, i32)
 _sig("ser_resample", i32, vp, i32, i32, i32, i32, i32, f32, vp, vp)
 _sig("ser_add_noise_snr", i32, vp, i32, i32, vp, C.c_ulonglong, vp, vp, vp)

@@ -31,6 +31,7 @@ struct SerGemmF32Args {
   float* ws;
   float* ws_rowsum;
   int vec_a, vec_b;   // set by the launcher: the contiguous axis of a / b is 16-byte aligned per float4 group
+  int products;       // MFMA products per multiply on the split-bf16 path: 3 (hi*hi + lo*hi + hi*lo, ~fp32) or 1 (bf16 operands)
 };
 
 namespace {
@@ -603,9 +604,12 @@ constexpr int X3_BK = 64;
 SER_DEVFN int x3_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 constexpr int X3_PLANE = 64 * 128;                   // bytes
-template <int AKF, int BKF>
-SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, const int bz, char (*lds)[4 * X3_PLANE]) {
+// NP = 3: A and B as hi/lo planes, three MFMAs per product.  NP = 1: hi planes only (operands rounded to bf16, fp32
+// accumulation) - used for the backward products of the token-level head GEMMs in the `bf16` precision mode.
+template <int AKF, int BKF, int NP = 3>
+SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, const int bz, char (*lds)[(NP == 3 ? 4 : 2) * X3_PLANE]) {
   constexpr int PLANE = X3_PLANE;
+  constexpr int BOFF = (NP == 3 ? 2 : 1) * PLANE;       // first plane of B inside a stage
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = by * 64, n0 = bx * 64;
@@ -635,14 +639,19 @@ SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, cons
     }
   };
   auto store_one = [&](char* hi, char* lo, const float4 v, int gi, bool kf) {
-    uint32_t h0, l0, h1, l1;
-    split_bf16x2(v.x, v.y, h0, l0);
-    split_bf16x2(v.z, v.w, h1, l1);
+    uint32_t h0, l0 = 0, h1, l1 = 0;
+    if (NP == 3) {
+      split_bf16x2(v.x, v.y, h0, l0);
+      split_bf16x2(v.z, v.w, h1, l1);
+    } else {
+      h0 = pack_bf16x2(v.x, v.y);
+      h1 = pack_bf16x2(v.z, v.w);
+    }
     if (kf) {
       const int r = gi / 16, k = (gi % 16) * 4;
       const int off = x3_off(r, k >> 3) + (k & 7) * 2;
       *(uint2*)(hi + off) = make_uint2(h0, h1);
-      *(uint2*)(lo + off) = make_uint2(l0, l1);
+      if (NP == 3) *(uint2*)(lo + off) = make_uint2(l0, l1);
     } else {
       const int k = gi / 16, r = (gi % 16) * 4;
       const int kb = (k & 7) * 2, ch = k >> 3;
@@ -650,10 +659,12 @@ SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, cons
       *(uint16_t*)(hi + x3_off(r + 1, ch) + kb) = (uint16_t)(h0 >> 16);
       *(uint16_t*)(hi + x3_off(r + 2, ch) + kb) = (uint16_t)h1;
       *(uint16_t*)(hi + x3_off(r + 3, ch) + kb) = (uint16_t)(h1 >> 16);
-      *(uint16_t*)(lo + x3_off(r, ch) + kb) = (uint16_t)l0;
-      *(uint16_t*)(lo + x3_off(r + 1, ch) + kb) = (uint16_t)(l0 >> 16);
-      *(uint16_t*)(lo + x3_off(r + 2, ch) + kb) = (uint16_t)l1;
-      *(uint16_t*)(lo + x3_off(r + 3, ch) + kb) = (uint16_t)(l1 >> 16);
+      if (NP == 3) {
+        *(uint16_t*)(lo + x3_off(r, ch) + kb) = (uint16_t)l0;
+        *(uint16_t*)(lo + x3_off(r + 1, ch) + kb) = (uint16_t)(l0 >> 16);
+        *(uint16_t*)(lo + x3_off(r + 2, ch) + kb) = (uint16_t)l1;
+        *(uint16_t*)(lo + x3_off(r + 3, ch) + kb) = (uint16_t)(l1 >> 16);
+      }
     }
   };
   auto store = [&](int buf, int k0) {
@@ -668,8 +679,8 @@ SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, cons
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      store_one(s, s + PLANE, ra[e], tid + 256 * e, AKF != 0);
-      store_one(s + 2 * PLANE, s + 3 * PLANE, rb[e], tid + 256 * e, BKF != 0);
+      store_one(s, s + PLANE, ra[e], tid + 256 * e, AKF != 0);                                  // NP == 1: the lo pointer is unused
+      store_one(s + BOFF, s + BOFF + PLANE, rb[e], tid + 256 * e, BKF != 0);
     }
   };
 
@@ -683,9 +694,14 @@ SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, cons
     if (want_rowsum) {
 #pragma unroll
       for (int ch = 0; ch < 8; ++ch) {
-        const bf16x8 h = *(const bf16x8*)(s + x3_off(tid, ch)), l = *(const bf16x8*)(s + PLANE + x3_off(tid, ch));
+        const bf16x8 h = *(const bf16x8*)(s + x3_off(tid, ch));
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rowsum += bf2f((bf16_t)h[e]) + bf2f((bf16_t)l[e]);
+        for (int e = 0; e < 8; ++e) rowsum += bf2f((bf16_t)h[e]);
+        if (NP == 3) {
+          const bf16x8 l = *(const bf16x8*)(s + PLANE + x3_off(tid, ch));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) rowsum += bf2f((bf16_t)l[e]);
+        }
       }
     }
 #pragma unroll
@@ -695,20 +711,22 @@ SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, cons
       for (int i = 0; i < 2; ++i) {
         const int off = x3_off(wm * 32 + i * 16 + fr, ks * 4 + fq);
         ah[i] = *(const bf16x8*)(s + off);
-        al[i] = *(const bf16x8*)(s + PLANE + off);
+        if (NP == 3) al[i] = *(const bf16x8*)(s + PLANE + off);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int off = x3_off(wn * 32 + j * 16 + fr, ks * 4 + fq);
-        bh[j] = *(const bf16x8*)(s + 2 * PLANE + off);
-        bl[j] = *(const bf16x8*)(s + 3 * PLANE + off);
+        bh[j] = *(const bf16x8*)(s + BOFF + off);
+        if (NP == 3) bl[j] = *(const bf16x8*)(s + BOFF + PLANE + off);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          if (NP == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -739,10 +757,10 @@ SER_DEVFN void x3_body(const SerGemmF32Args& g, const int bx, const int by, cons
 }
 
 
-template <int AKF, int BKF>
+template <int AKF, int BKF, int NP = 3>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const SerGemmF32Args g) {
-  __shared__ __attribute__((aligned(16))) char lds[2][4 * X3_PLANE];   // [stage][A_hi, A_lo, B_hi, B_lo] = 64 KB
-  x3_body<AKF, BKF>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+  __shared__ __attribute__((aligned(16))) char lds[2][(NP == 3 ? 4 : 2) * X3_PLANE];   // [stage][A_hi, (A_lo,) B_hi(, B_lo)]
+  x3_body<AKF, BKF, NP>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds);
 }
 
 // Grouped token-level weight gradients: up to 32 independent dW = dy^T x problems (split over their token
@@ -758,8 +776,9 @@ struct WgradGroup {
   WgradGroupProb p[SER_WGRAD_GROUP];
   int nprob;
 };
+template <int NP>
 __global__ __launch_bounds__(256) void gemm_x3_group_kernel(const WgradGroup G) {
-  __shared__ __attribute__((aligned(16))) char lds[2][4 * X3_PLANE];
+  __shared__ __attribute__((aligned(16))) char lds[2][(NP == 3 ? 4 : 2) * X3_PLANE];
   int pi = 0;
   for (int i = 1; i < G.nprob; ++i)
     if ((int)blockIdx.z >= G.p[i].z0) pi = i;
@@ -769,8 +788,8 @@ __global__ __launch_bounds__(256) void gemm_x3_group_kernel(const WgradGroup G) 
   g.a = P.dy; g.b = P.x; g.c = nullptr; g.M = P.N; g.N = P.K; g.K = P.M;
   g.sam = 1; g.sak = P.N; g.sbk = P.K; g.sbn = 1; g.ldc = P.K;
   g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = 0;
-  g.k_chunk = 256; g.ws = P.ws; g.ws_rowsum = P.ws_rowsum; g.vec_a = g.vec_b = 1;
-  x3_body<0, 0>(g, blockIdx.x, blockIdx.y, (int)blockIdx.z - P.z0, lds);
+  g.k_chunk = 256; g.ws = P.ws; g.ws_rowsum = P.ws_rowsum; g.vec_a = g.vec_b = 1; g.products = NP;
+  x3_body<0, 0, NP>(g, blockIdx.x, blockIdx.y, (int)blockIdx.z - P.z0, lds);
 }
 
 struct ReduceGroupProb {
@@ -822,6 +841,16 @@ static void launch_6464_bk(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
 }
 static int g_f32_bk_fwd();
 static int g_use_x3 = 1;   // token-level head products on split-bf16 MFMA (0: exact fp32 MFMA)
+// MFMA products per multiply in the BACKWARD token-level head GEMMs (dgrad, wgrad): 3 = fp32-equivalent (default, parity
+// mode), 1 = bf16 operands with fp32 accumulation (the `bf16` precision mode of the system: what mixed-precision
+// training does for every matmul).  Forward products always use 3: the 1e-3 logit budget is a forward bound.
+static int g_head_bwd_products = 3;
+extern "C" int ser_set_head_backward_products(int n) {
+  SER_REQUIRE(n == 1 || n == 3, "head backward products must be 1 or 3");
+  g_head_bwd_products = n;
+  return SER_OK;
+}
+extern "C" int ser_get_head_backward_products(void) { return g_head_bwd_products; }
 extern "C" int ser_debug_set_head_x3(int v) { g_use_x3 = v; return 0; }
 
 static void launch_6464(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
@@ -833,10 +862,17 @@ static void launch_6464(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
     const bool ok = g_use_x3 && g.vec_a && g.vec_b && ktail_ok && (!g.k_chunk || g.k_chunk % X3_BK == 0) && g.M >= 4 && g.N >= 4;
     if (ok && (ak || g.sam == 1) && (bk || g.sbn == 1)) {
       dim3 block(256);
-      if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 1>), grid, block, 0, st, g);
-      else if (ak && !bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 0>), grid, block, 0, st, g);
-      else if (!ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<0, 1>), grid, block, 0, st, g);
-      else hipLaunchKernelGGL((gemm_x3_kernel<0, 0>), grid, block, 0, st, g);
+      if (g.products == 1) {
+        if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 1, 1>), grid, block, 0, st, g);
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 0, 1>), grid, block, 0, st, g);
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<0, 1, 1>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_x3_kernel<0, 0, 1>), grid, block, 0, st, g);
+      } else {
+        if (ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 1>), grid, block, 0, st, g);
+        else if (ak && !bk) hipLaunchKernelGGL((gemm_x3_kernel<1, 0>), grid, block, 0, st, g);
+        else if (!ak && bk) hipLaunchKernelGGL((gemm_x3_kernel<0, 1>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((gemm_x3_kernel<0, 0>), grid, block, 0, st, g);
+      }
       return;
     }
   }
@@ -887,7 +923,16 @@ extern "C" int ser_gemm_f32(const float* a, long long sam, long long sak, const 
   g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr; g.accumulate = accumulate;
-  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0;
+  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0; g.products = 3;
+  return ser_launch_gemm_f32(g, (hipStream_t)stream);
+}
+static int gemm_f32_bwd(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn, int M, int N,
+                        int K, float* c, int ldc, int accumulate, void* stream) {
+  SerGemmF32Args g;
+  g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K;
+  g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
+  g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = accumulate;
+  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0; g.products = g_head_bwd_products;
   return ser_launch_gemm_f32(g, (hipStream_t)stream);
 }
 
@@ -941,7 +986,7 @@ extern "C" int ser_linear_dgrad(const float* dy, const float* W, const float* re
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
-  SER_TRY(ser_gemm_f32(dy, N, 1, W, K, 1, M, K, N, nullptr, SER_ACT_NONE, nullptr, 0, dx, K, accumulate, stream));
+  SER_TRY(gemm_f32_bwd(dy, N, 1, W, K, 1, M, K, N, dx, K, accumulate, stream));
   if (relu_mask) {
     SER_REQUIRE(!accumulate, "linear_dgrad: relu_mask with accumulate needs the skinny path");
     return ser_act_bwd(dx, relu_mask, SER_ACT_RELU, (long long)M * K, dx, stream);
@@ -1048,7 +1093,8 @@ extern "C" int ser_linear_wgrad_group(const void* const* ptrs, const int* dims, 
     gx = gx > ceil_div(K, 64) ? gx : ceil_div(K, 64);
     gy = gy > ceil_div(N, 64) ? gy : ceil_div(N, 64);
   }
-  hipLaunchKernelGGL(gemm_x3_group_kernel, dim3(gx, gy, z), dim3(256), 0, st, G);
+  if (g_head_bwd_products == 1) hipLaunchKernelGGL(gemm_x3_group_kernel<1>, dim3(gx, gy, z), dim3(256), 0, st, G);
+  else hipLaunchKernelGGL(gemm_x3_group_kernel<3>, dim3(gx, gy, z), dim3(256), 0, st, G);
   hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)(off / 256)), dim3(256), 0, st, R, accumulate);
   SER_LAUNCH_CHECK();
   return SER_OK;
@@ -1113,7 +1159,7 @@ extern "C" int ser_linear_wgrad(const float* dy, const float* x, float* dW, floa
   g.a = dy; g.b = x; g.c = dW; g.M = N; g.N = K; g.K = M;
   g.sam = 1; g.sak = N; g.sbk = K; g.sbn = 1; g.ldc = K;
   g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = accumulate;
-  g.k_chunk = chunk; g.vec_a = g.vec_b = 0;
+  g.k_chunk = chunk; g.vec_a = g.vec_b = 0; g.products = g_head_bwd_products;
   g.ws = (float*)workspace;
   g.ws_rowsum = db ? g.ws + (size_t)splits * N * K : nullptr;
   SER_TRY(ser_launch_gemm_f32(g, st));

@@ -38,6 +38,10 @@ class SERSystem(nn.Module):
         self.num_labels = num_labels
         self._graph = None
         self._side = None
+        # `bf16` precision mode: the backward token-level head GEMMs round their operands to bf16 (one MFMA product
+        # per multiply, fp32 accumulation), as the frozen encoders do; `bf16x3` keeps the fp32-equivalent 3-product
+        # form everywhere.  Forward products of the head always use the 3-product form (1e-3 logit budget).
+        self.head_backward_products = 1 if getattr(audio_encoder, "precision", "bf16x3") == "bf16" else 3
 
     # ---- reference checkpoint layout (train.py:249-262) ---------------------------------------------------------
     CKPT_KEYS = ("audio_encoder", "text_encoder", "cross", "pool_a", "pool_t", "fusion", "classifier", "prototypes")
@@ -94,9 +98,14 @@ class SERSystem(nn.Module):
         from ._engines import forward_pair
         return forward_pair(self.audio_encoder.engine(), self.text_encoder.engine(), wave, ids, attn_mask)
 
+    def _set_precision(self):
+        from . import _lib as L
+        L.check(L.lib.ser_set_head_backward_products(self.head_backward_products), "ser_set_head_backward_products")
+
     def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True):
         """Everything trainable: adapters -> cross-attention -> pooling -> fusion -> classifier -> loss."""
         from .models.adapter import adapter_apply
+        self._set_precision()
         cur = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
@@ -135,6 +144,7 @@ class SERSystem(nn.Module):
         return self.classifier(fused, use_openmax=use_openmax)
 
     def loss(self, wave, ids, attn_mask, labels, use_proto=True):
+        self._set_precision()
         fused = self.head(*self.encode(wave, ids, attn_mask))
         logits, unc, anchor = self.classifier(fused, use_openmax=False, return_uncertainty=True)
         total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)

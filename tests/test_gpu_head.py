@@ -283,3 +283,38 @@ def test_classifier_persistent_stack_equals_per_block_launches(M, rows, D, depth
     a2 = run(True, twice=True)
     for k in a2[2]:
         same(a2[2][k], 2 * a[2][k], "accumulated " + k)
+
+
+@pytest.mark.parametrize("M_,N,K", [(3184, 256, 768), (512, 768, 256), (130, 72, 36)])
+def test_backward_token_gemms_in_one_product_mode(M, M_, N, K):
+    """`bf16` precision mode: dgrad / wgrad of the token-level Linears round their operands to bf16 (one MFMA product,
+    fp32 accumulation).  Against float64 on the bf16-rounded operands they are exact to fp32 accumulation error;
+    against the unrounded operands the error is the bf16 operand rounding (~2^-9 relative per factor)."""
+    from ser_amd import _lib as L, _ops as OP
+    g = torch.Generator().manual_seed(M_ + N)
+    dy = torch.randn(M_, N, generator=g).cuda()
+    x = torch.randn(M_, K, generator=g).cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bf = lambda t_: t_.to(torch.bfloat16).double()
+    try:
+        L.check(L.lib.ser_set_head_backward_products(1), "set")
+        assert L.lib.ser_get_head_backward_products() == 1
+        dx = OP.linear_dgrad(dy, W)
+        dW, db = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+        OP.linear_wgrad(dy, x, dW, db)
+        torch.cuda.synchronize()
+    finally:
+        L.lib.ser_set_head_backward_products(3)
+    if N % 64 == 0 and K % 64 == 0:      # shapes the split-bf16 MFMA kernels take (others fall back to exact fp32 MFMA)
+        ref_dx, ref_dW = bf(dy) @ bf(W), bf(dy).t() @ bf(x)
+        assert (dx.double() - ref_dx).abs().max().item() < 2e-4 * (N ** 0.5)
+        assert (dW.double() - ref_dW).abs().max().item() < 2e-4 * (M_ ** 0.5)
+        assert (db.double() - bf(dy).sum(0)).abs().max().item() < 2e-4 * (M_ ** 0.5)
+    fullW = dy.double().t() @ x.double()
+    assert (dW.double() - fullW).abs().max().item() < 4e-2 * fullW.abs().max().item()
+    # and the bf16 rounding itself stays at the 1e-3 level of the result's scale
+    full = dy.double() @ W.double()
+    assert (dx.double() - full).abs().max().item() < 4e-2 * full.abs().max().item()
+    # 3-product default: fp32-equivalent
+    dx3 = OP.linear_dgrad(dy, W)
+    assert (dx3.double() - full).abs().max().item() < 2e-4 * full.abs().max().item()
