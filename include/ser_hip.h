@@ -226,10 +226,14 @@ int ser_linear_fwd_ln2(const float* x, const float* W, const float* bias, int ac
 int ser_stack_supported(int L, int M, int D);
 size_t ser_stack_scratch_bytes(int D);
 int ser_stack_fwd(const void* ptr_table, const float* x0, float* Hs, float* X1, float* U, float* A, float* ST, int L,
-                  int M, int D, float eps, void* scratch, void* stream);
+                  int M, int D, float eps, void* scratch, const void* drop_state, unsigned drop_site, float drop_p,
+                  void* stream);
+/* drop_state / drop_site / drop_p: the two nn.Dropout layers of every block in training mode (see ser_dropout; site ids
+ * drop_site + 2 i and + 2 i + 1 for block i; NULL state or p = 0: identity).  With dropout, DT[L+1][M][D] receives the
+ * dropped block-output gradients (operand of dW2 = DT^T a); otherwise it may be NULL and DH plays that role. */
 int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const float* X1, const float* A,
                   const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* scratch,
-                  void* stream);
+                  const void* drop_state, unsigned drop_site, float drop_p, float* DT, void* stream);
 int ser_stack_ln_param_bwd(const void* grad_table, const float* x0, const float* Hs, const float* X1, const float* ST,
                            const float* DU, const float* DX1, int L, int M, int D, int accumulate, void* stream);
 /* Precision of the BACKWARD token-level (M > 16) head products (ser_linear_dgrad, ser_linear_wgrad*): 3 MFMA products
@@ -274,12 +278,15 @@ int ser_scale_dev(float* x, const float* s, long long n, void* stream);         
 
 /* softmax(q k^T / sqrt(hd) + key mask) v of nn.MultiheadAttention (cross_attention.py:41,49;
  * torch nn/functional.py multi_head_attention_forward).  P [B,heads,Sq,Sk] is kept for backward. */
-int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
-                  const float* key_mask, int B, int Sq, int Sk, int heads, int head_dim, float* P,
-                  float* ctx, int ldc, void* stream);
-int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk,
-                  const float* v, int ldv, const float* P, int B, int Sq, int Sk, int heads, int head_dim,
-                  float* dS, float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, void* stream);
+int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* key_mask, int B,
+                  int Sq, int Sk, int heads, int head_dim, float* P, float* ctx, int ldc, const void* drop_state,
+                  unsigned drop_site, float drop_p, void* stream);
+/* drop_*: nn.MultiheadAttention's attention dropout in training mode (ctx = (P * m / (1 - p)) v; P as stored is the
+ * softmax output; see ser_dropout for the generator; NULL state or p = 0: identity). */
+int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                  const float* P, int B, int Sq, int Sk, int heads, int head_dim, float* dS, float* dq, int lddq,
+                  float* dk, int lddk, float* dv, int lddv, const void* drop_state, unsigned drop_site, float drop_p,
+                  void* stream);
 
 /* AttentiveStatsPooling core (pooling.py:21-28): masked softmax over time of `logits`, weighted
  * mean and std -> out [B,2D]; alpha [B,S] kept for backward. */
@@ -307,6 +314,12 @@ int ser_train_loss(const float* logits, const float* unc, const float* fused, co
 int ser_openmax(const float* feats, const float* act_vec, const float* walpha, const float* wbeta,
                 const float* wtau, int B, int C, int F, float thresh, float reduce, float* logits,
                 void* stream);
+
+/* nn.Dropout(p) in training mode (cross_attention.py:28,43,51; fusion.py:9,12; classifier.py:83,85,109,127,195):
+ * y = x * m / (1 - p), m ~ Bernoulli(1 - p) from a counter-based generator keyed by (*state, site, element index).
+ * `state` is a device word advanced by the host once per training step, `site` names the layer; the backward pass
+ * calls the same function on the gradient (the mask is regenerated, never stored).  state == NULL or p == 0: copy. */
+int ser_dropout(const float* x, long long n, const void* state, unsigned site, float p, float* y, void* stream);
 
 /* torch.optim.AdamW update of a flat fp32 segment (train.py:72-83,169-177).
  * hyper (device) = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; effective lr = hyper[0] * lr_mult. */

@@ -171,13 +171,14 @@ _sig("ser_get_head_backward_products", i32)
 _sig("ser_resample_out_len", i32, i32, i32, i32)
 _sig("ser_resample", i32, vp, i32, i32, i32, i32, i32, f32, vp, vp)
 _sig("ser_add_noise_snr", i32, vp, i32, i32, vp, C.c_ulonglong, vp, vp, vp)
+_sig("ser_dropout", i32, vp, C.c_longlong, vp, C.c_uint, f32, vp, vp)
 _sig("ser_adamw_multi", i32, vp, vp, vp, vp, i32, vp, f32, f32, f32, vp)
 _sig("ser_gemm_tile_hint", i32, C.c_longlong, i32, i32, i32)
 _sig("ser_debug_set_gemm_bm", i32, i32)
 _sig("ser_stack_supported", i32, i32, i32, i32)
 _sig("ser_stack_scratch_bytes", sz, i32)
-_sig("ser_stack_fwd", i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp)
-_sig("ser_stack_bwd", i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp)
+_sig("ser_stack_fwd", i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, C.c_uint, f32, vp)
+_sig("ser_stack_bwd", i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, C.c_uint, f32, vp, vp)
 _sig("ser_stack_ln_param_bwd", i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
 _sig("ser_linear_wgrad_pair", i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp)
 _sig("ser_layernorm2_fwd", i32, vp, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp, vp)
@@ -192,8 +193,8 @@ _sig("ser_act_fwd", i32, vp, i32, i64, vp, vp)
 _sig("ser_act_bwd", i32, vp, vp, i32, i64, vp, vp)
 _sig("ser_axpby", i32, vp, f32, f32, i64, vp, vp)
 _sig("ser_scale_dev", i32, vp, vp, i64, vp)
-_sig("ser_xattn_fwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp)
-_sig("ser_xattn_bwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp)
+_sig("ser_xattn_fwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, C.c_uint, f32, vp)
+_sig("ser_xattn_bwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, C.c_uint, f32, vp)
 _sig("ser_pool_fwd", i32, vp, vp, vp, i32, i32, i32, vp, vp, vp)
 _sig("ser_pool_bwd", i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp)
 _sig("ser_fusion_mix_fwd", i32, vp, vp, vp, vp, i32, i32, vp, vp)

@@ -187,24 +187,30 @@ def stack_supported(L_, M, D):
     return USE_STACK and bool(L.lib.ser_stack_supported(L_, M, D))
 
 
-def stack_fwd(x0, table, L_, flags, eps=1e-5):
-    """All L residual blocks forward -> (Hs[L,M,D] block outputs, X1, U, A [L,M,D], ST[L,4,M])."""
+def stack_fwd(x0, table, L_, flags, eps=1e-5, dctx=None, site=0):
+    """All L residual blocks forward -> (Hs[L,M,D] block outputs, X1, U, A [L,M,D], ST[L,4,M]).  dctx / site: the two
+    dropout layers of every block in training mode (sites site + 2 i, site + 2 i + 1)."""
     M, D = x0.shape
     Hs, X1, U, A = (empty(L_, M, D, like=x0) for _ in range(4))
     ST = empty(L_, 4, M, like=x0)
+    state, p = dctx if dctx is not None else (None, 0.0)
     L.check(L.lib.ser_stack_fwd(L.ptr(table), L.ptr(x0), L.ptr(Hs), L.ptr(X1), L.ptr(U), L.ptr(A), L.ptr(ST), L_, M, D, eps,
-                                L.ptr(flags), L.stream_ptr()), "ser_stack_fwd")
+                                L.ptr(flags), L.ptr(state), int(site), p, L.stream_ptr()), "ser_stack_fwd")
     return Hs, X1, U, A, ST
 
 
-def stack_bwd(table, x0, Hs, X1, A, ST, DH, flags):
+def stack_bwd(table, x0, Hs, X1, A, ST, DH, flags, dctx=None, site=0):
     """Backward dgrad chain of the stack.  DH[L] holds the gradient at the stack output on entry; on return DH[i] is
-    the gradient at the input of block i (DH[0]: at x0).  -> DA, DU, DX1 [L,M,D] for the batched parameter gradients."""
+    the gradient at the input of block i (DH[0]: at x0).  -> DA, DU, DX1 [L,M,D] for the batched parameter gradients,
+    and DT [L+1,M,D] (the dropped block-output gradients) when dropout is active, else None."""
     L_, M, D = Hs.shape
     DA, DU, DX1 = (empty(L_, M, D, like=x0) for _ in range(3))
+    state, p = dctx if dctx is not None else (None, 0.0)
+    DT = empty(L_ + 1, M, D, like=x0) if dctx is not None else None
     L.check(L.lib.ser_stack_bwd(L.ptr(table), L.ptr(x0), L.ptr(Hs), L.ptr(X1), L.ptr(A), L.ptr(ST), L.ptr(DH), L.ptr(DA),
-                                L.ptr(DU), L.ptr(DX1), L_, M, D, L.ptr(flags), L.stream_ptr()), "ser_stack_bwd")
-    return DA, DU, DX1
+                                L.ptr(DU), L.ptr(DX1), L_, M, D, L.ptr(flags), L.ptr(state), int(site), p, L.ptr(DT),
+                                L.stream_ptr()), "ser_stack_bwd")
+    return DA, DU, DX1, DT
 
 
 def stack_ln_param_bwd(gtable, x0, Hs, X1, ST, DU, DX1, accumulate=False):
@@ -291,26 +297,29 @@ def ln_bwd(dy, saved, gamma, dgamma=None, dbeta=None, accumulate=False, dx_add=N
     return dx
 
 
-def xattn_fwd(q, k, v, key_mask, B, Sq, Sk, heads):
-    """q [B*Sq,E], k,v [B*Sk,E] (may be column slices given as (tensor, ld) through .stride) -> ctx, P."""
+def xattn_fwd(q, k, v, key_mask, B, Sq, Sk, heads, dctx=None, site=0):
+    """q [B*Sq,E], k,v [B*Sk,E] (may be column slices given as (tensor, ld) through .stride) -> ctx, P.
+    dctx / site: attention-probability dropout (training mode)."""
     E = q.shape[1]
     hd = E // heads
     P = empty(B, heads, Sq, Sk, like=q)
     ctx = empty(B * Sq, E, like=q)
+    state, p = dctx if dctx is not None else (None, 0.0)
     L.check(L.lib.ser_xattn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                L.ptr(key_mask), B, Sq, Sk, heads, hd, L.ptr(P), L.ptr(ctx), E, L.stream_ptr()),
-            "ser_xattn_fwd")
+                                L.ptr(key_mask), B, Sq, Sk, heads, hd, L.ptr(P), L.ptr(ctx), E, L.ptr(state), int(site), p,
+                                L.stream_ptr()), "ser_xattn_fwd")
     return ctx, P
 
 
-def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads):
+def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads, drop=None, site=0):
     E = q.shape[1]
     hd = E // heads
     dS = torch.empty_like(P)
     dq, dk, dv = empty(B * Sq, E, like=q), empty(B * Sk, E, like=q), empty(B * Sk, E, like=q)
     L.check(L.lib.ser_xattn_bwd(L.ptr(dctx), E, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                 v.stride(0), L.ptr(P), B, Sq, Sk, heads, hd, L.ptr(dS), L.ptr(dq), E, L.ptr(dk), E, L.ptr(dv),
-                                E, L.stream_ptr()), "ser_xattn_bwd")
+                                E, L.ptr(drop[0] if drop is not None else None), int(site), drop[1] if drop is not None else 0.0,
+                                L.stream_ptr()), "ser_xattn_bwd")
     return dq, dk, dv
 
 
@@ -367,6 +376,50 @@ def openmax_(feats, act_vec, walpha, wbeta, wtau, logits, thresh=0.3, reduce=0.8
     L.check(L.lib.ser_openmax(L.ptr(feats), L.ptr(act_vec), L.ptr(walpha), L.ptr(wbeta), L.ptr(wtau), B, C, F, thresh,
                               reduce, L.ptr(logits), L.stream_ptr()), "ser_openmax")
     return logits
+
+
+# ---- dropout (training mode) ----------------------------------------------------------------------------------------
+# Off by default: module-level parity is defined with dropout as the identity (the golden vectors of the reference were
+# captured that way).  `SERSystem` turns it on around its training forward (`dropout_scope`); every autograd node reads the
+# state at forward time and keeps what it needs for backward, so the switch only has to cover the forward call.
+_DROP = {"on": False, "state": None}
+_SITES = [0]
+
+
+def new_dropout_site(n=1):
+    """A process-unique id for one dropout layer (part of the mask generator's key); n > 1 reserves a run of ids and
+    returns the first."""
+    first = _SITES[0] + 1
+    _SITES[0] += n
+    return first
+
+
+class dropout_scope:
+    def __init__(self, state):
+        self.state = state          # device int64[1]: the generator state, advanced once per step by the owner
+
+    def __enter__(self):
+        self.prev = dict(_DROP)
+        _DROP["on"], _DROP["state"] = self.state is not None, self.state
+
+    def __exit__(self, *a):
+        _DROP.update(self.prev)
+
+
+def dropout_ctx(p):
+    """-> (state tensor, p) when dropout is active, else None."""
+    if _DROP["on"] and p > 0.0:
+        return (_DROP["state"], float(p))
+    return None
+
+
+def dropout_(x, dctx, site):
+    """In place: x *= mask / (1 - p).  The same call on a gradient is the backward of the layer."""
+    if dctx is None:
+        return x
+    state, p = dctx
+    L.check(L.lib.ser_dropout(L.ptr(x), x.numel(), L.ptr(state), int(site), p, L.ptr(x), L.stream_ptr()), "ser_dropout")
+    return x
 
 
 def adamw_multi_(segments, hyper, b1, b2, eps):

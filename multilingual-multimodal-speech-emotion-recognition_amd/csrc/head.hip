@@ -392,11 +392,32 @@ __global__ void axpby_kernel(const float* __restrict__ x, float a, float b, long
 // ------------------------------------------------------------------------------------------
 constexpr int XA_MAXK = 1536;   // keys per row held in LDS (30 s of audio = 1499 frames)
 
+// attention-probability dropout (nn.MultiheadAttention(dropout=p), training mode): ctx uses P * m / (1 - p); the stored P
+// stays the softmax output (its backward needs it) and the mask is regenerated from the element index in backward
+struct XDrop {
+  bool on;
+  unsigned long long st;
+  unsigned site, thresh;
+  float scale;
+};
+SER_DEVFN XDrop xdrop_init(const SerDropout& d) {
+  XDrop x;
+  x.on = d.state != nullptr && d.p > 0.f;
+  x.st = x.on ? *d.state : 0ull;
+  x.site = d.site; x.thresh = ser_drop_thresh(d.p); x.scale = 1.0f / (1.0f - d.p);
+  return x;
+}
+SER_DEVFN float xdrop_mult(const XDrop& x, long long idx) {
+  return x.on ? ser_drop_mult(x.st, x.site, (unsigned)idx, x.thresh, x.scale) : 1.0f;
+}
+
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                         int ldk, const float* __restrict__ v, int ldv,
                                                         const float* __restrict__ kmask, int B, int Sq, int Sk, int heads,
-                                                        int hd, float* __restrict__ P, float* __restrict__ ctx, int ldc) {
+                                                        int hd, float* __restrict__ P, float* __restrict__ ctx, int ldc,
+                                                        SerDropout drop) {
   __shared__ float ps[4][XA_MAXK];
+  const XDrop xd = xdrop_init(drop);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long row = (long long)blockIdx.x * 4 + w;   // over B*heads*Sq
   if (row >= (long long)B * heads * Sq) return;
@@ -428,9 +449,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
   sum = wave_sum(sum);
   const float inv = sum > 0.f ? 1.0f / sum : 0.f;
   float* Pr = P + (((long long)b * heads + h) * Sq + i) * Sk;
+  const long long prow0 = (((long long)b * heads + h) * Sq + i) * Sk;
   for (int j = lane; j < Sk; j += 64) {
     const float p = ps[w][j] * inv;
-    ps[w][j] = p;
+    ps[w][j] = p * xdrop_mult(xd, prow0 + j);
     Pr[j] = p;
   }
   __builtin_amdgcn_wave_barrier();
@@ -447,8 +469,10 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_kernel(const float* __restric
                                                           const float* __restrict__ k, int ldk,
                                                           const float* __restrict__ v, int ldv,
                                                           const float* __restrict__ P, int B, int Sq, int Sk, int heads,
-                                                          int hd, float* __restrict__ dS, float* __restrict__ dq, int ldq) {
+                                                          int hd, float* __restrict__ dS, float* __restrict__ dq, int ldq,
+                                                          SerDropout drop) {
   __shared__ float ds[4][XA_MAXK];
+  const XDrop xd = xdrop_init(drop);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long row = (long long)blockIdx.x * 4 + w;
   if (row >= (long long)B * heads * Sq) return;
@@ -463,6 +487,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_kernel(const float* __restric
     const float* vr = v + ((long long)b * Sk + j) * ldv + h * hd;
     float acc = 0.f;
     for (int d = 0; d < hd; ++d) acc = fmaf(dc[d], vr[d], acc);
+    acc *= xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j);     // gradient at the un-dropped probability
     ds[w][j] = acc;
     dot = fmaf(Pr[j], acc, dot);
   }
@@ -487,7 +512,9 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
                                                            const float* __restrict__ q, int ldq,
                                                            const float* __restrict__ P, const float* __restrict__ dS,
                                                            int B, int Sq, int Sk, int heads, int hd,
-                                                           float* __restrict__ dk, int ldk, float* __restrict__ dv, int ldv) {
+                                                           float* __restrict__ dk, int ldk, float* __restrict__ dv, int ldv,
+                                                           SerDropout drop) {
+  const XDrop xd = xdrop_init(drop);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long row = (long long)blockIdx.x * 4 + w;   // over B*heads*Sk
   if (row >= (long long)B * heads * Sk) return;
@@ -504,7 +531,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
     if (d < hd) {
       float acc = 0.f;
       for (int i = 0; i < Sq; ++i) {
-        const float wgt = isv ? Pc[(long long)i * Sk] : Sc[(long long)i * Sk];
+        const float wgt = isv ? Pc[(long long)i * Sk] * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j) : Sc[(long long)i * Sk];
         const float* src = isv ? dctx + ((long long)b * Sq + i) * ldc : q + ((long long)b * Sq + i) * ldq;
         acc = fmaf(wgt, src[h * hd + d], acc);
       }
@@ -515,7 +542,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
     float ak = 0.f, av = 0.f;
     for (int i = 0; i < Sq; ++i) {
       ak = fmaf(Sc[(long long)i * Sk], q[((long long)b * Sq + i) * ldq + h * hd + lane], ak);
-      av = fmaf(Pc[(long long)i * Sk], dctx[((long long)b * Sq + i) * ldc + h * hd + lane], av);
+      av = fmaf(Pc[(long long)i * Sk] * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j),
+                dctx[((long long)b * Sq + i) * ldc + h * hd + lane], av);
     }
     dk[((long long)b * Sk + j) * ldk + h * hd + lane] = ak * scale;
     dv[((long long)b * Sk + j) * ldv + h * hd + lane] = av;
@@ -535,7 +563,9 @@ constexpr int XF_MAXS = 256, XF_HD = 32, XF_LD = XF_MAXS + 1;
 __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                              int ldk, const float* __restrict__ v, int ldv,
                                                              const float* __restrict__ kmask, int Sq, int Sk, int heads,
-                                                             float* __restrict__ P, float* __restrict__ ctx, int ldc) {
+                                                             float* __restrict__ P, float* __restrict__ ctx, int ldc,
+                                                             SerDropout drop) {
+  const XDrop xd = xdrop_init(drop);
   __shared__ float Kt[XF_HD][XF_LD];       // K^T: [d][key]
   __shared__ float Vs[XF_MAXS][XF_HD];     // V:   [key][d]
   __shared__ float prow[4][XF_MAXS];
@@ -581,7 +611,11 @@ __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = lane + 64 * u;
-      if (j < Sk) { const float p = sc[u] * inv; prow[w][j] = p; Pr[j] = p; }
+      if (j < Sk) {
+        const float p = sc[u] * inv;
+        prow[w][j] = p * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j);
+        Pr[j] = p;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -599,7 +633,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __rest
 __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ k,
                                                                int ldk, const float* __restrict__ v, int ldv,
                                                                const float* __restrict__ P, int Sq, int Sk, int heads,
-                                                               float* __restrict__ dS, float* __restrict__ dq, int ldq) {
+                                                               float* __restrict__ dS, float* __restrict__ dq, int ldq,
+                                                               SerDropout drop) {
+  const XDrop xd = xdrop_init(drop);
   __shared__ float Vt[XF_HD][XF_LD];       // V^T: [d][key]
   __shared__ float Ks[XF_MAXS][XF_HD];     // K:   [key][d]
   __shared__ float srow[4][XF_MAXS];
@@ -630,6 +666,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __re
         float acc = 0.f;
 #pragma unroll
         for (int d = 0; d < XF_HD; ++d) acc = fmaf(drow[w][d], Vt[d][j], acc);
+        acc *= xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j);
         dp[u] = acc; pp[u] = Pr[j];
         dot = fmaf(pp[u], acc, dot);
       }
@@ -657,7 +694,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __re
 __global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ q,
                                                                 int ldq, const float* __restrict__ P, const float* __restrict__ dS,
                                                                 int Sq, int Sk, int heads, float* __restrict__ dk, int ldk,
-                                                                float* __restrict__ dv, int ldv) {
+                                                                float* __restrict__ dv, int ldv, SerDropout drop) {
+  const XDrop xd = xdrop_init(drop);
   __shared__ float Qs[XF_MAXS][XF_HD];
   __shared__ float Ds[XF_MAXS][XF_HD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -676,7 +714,8 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __r
   for (int e = 0; e < 8; ++e) ak[e] = av[e] = 0.f;
   const int jj = j < Sk ? j : Sk - 1;
   for (int i = 0; i < Sq; ++i) {
-    const float p = Pc[(long long)i * Sk + jj], s = Sc[(long long)i * Sk + jj];     // coalesced over the 64 keys
+    const float p = Pc[(long long)i * Sk + jj] * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + jj);
+    const float s = Sc[(long long)i * Sk + jj];                                      // coalesced over the 64 keys
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       ak[e] = fmaf(s, Qs[i][w * 8 + e], ak[e]);       // LDS broadcast reads
@@ -1053,6 +1092,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// y = x * mask / (1 - p) for one dropout site (in place when y == x); forward and backward apply the same multiplier
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, long long n, SerDropout d, float* __restrict__ y) {
+  const unsigned long long st = *d.state;
+  const unsigned thresh = ser_drop_thresh(d.p);
+  const float scale = 1.0f / (1.0f - d.p);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = x[i] * ser_drop_mult(st, d.site, (unsigned)i, thresh, scale);
+}
+
 // the same update for up to 16 flat segments (one per optimizer group x bucket) in ONE launch: blockIdx.y = segment
 constexpr int ADAMW_MAX_SEG = 16;
 struct AdamwSeg {
@@ -1198,41 +1246,45 @@ extern "C" int ser_axpby(const float* x, float a, float b, long long n, float* y
 
 extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                              const float* key_mask, int B, int Sq, int Sk, int heads, int head_dim, float* P, float* ctx,
-                             int ldc, void* stream) {
+                             int ldc, const void* drop_state, unsigned drop_site, float drop_p, void* stream) {
   SER_REQUIRE(Sk <= XA_MAXK && head_dim <= 64 && head_dim > 0, "xattn: Sk=%d (max %d) head_dim=%d (max 64)", Sk, XA_MAXK, head_dim);
+  SER_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "xattn: dropout p=%f out of range", drop_p);
   const long long rows = (long long)B * heads * Sq;
   if (rows <= 0) return SER_OK;
+  const SerDropout drop{(const unsigned long long*)drop_state, drop_site, drop_p};
   if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
     hipLaunchKernelGGL(xattn_fwd_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
-                       v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc);
+                       v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc, drop);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
   hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
-                     ldv, key_mask, B, Sq, Sk, heads, head_dim, P, ctx, ldc);
+                     ldv, key_mask, B, Sq, Sk, heads, head_dim, P, ctx, ldc, drop);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
 
 extern "C" int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk, const float* v,
                              int ldv, const float* P, int B, int Sq, int Sk, int heads, int head_dim, float* dS,
-                             float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, void* stream) {
+                             float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, const void* drop_state,
+                             unsigned drop_site, float drop_p, void* stream) {
   SER_REQUIRE(Sk <= XA_MAXK && head_dim <= 64 && head_dim > 0, "xattn_bwd: Sk=%d head_dim=%d unsupported", Sk, head_dim);
   hipStream_t st = (hipStream_t)stream;
   const long long rq = (long long)B * heads * Sq, rk = (long long)B * heads * Sk;
   if (rq <= 0 || rk <= 0) return SER_OK;
+  const SerDropout drop{(const unsigned long long*)drop_state, drop_site, drop_p};
   if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
     hipLaunchKernelGGL(xattn_bwd_q_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
-                       Sq, Sk, heads, dS, dq, lddq);
+                       Sq, Sk, heads, dS, dq, lddq, drop);
     hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, P, dS, Sq,
-                       Sk, heads, dk, lddk, dv, lddv);
+                       Sk, heads, dk, lddk, dv, lddv, drop);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
   hipLaunchKernelGGL(xattn_bwd_q_kernel, dim3((unsigned)((rq + 3) / 4)), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P, B, Sq,
-                     Sk, heads, head_dim, dS, dq, lddq);
+                     Sk, heads, head_dim, dS, dq, lddq, drop);
   hipLaunchKernelGGL(xattn_bwd_kv_kernel, dim3((unsigned)((rk + 3) / 4)), dim3(256), 0, st, dctx, ldc, q, ldq, P, dS, B, Sq, Sk,
-                     heads, head_dim, dk, lddk, dv, lddv);
+                     heads, head_dim, dk, lddk, dv, lddv, drop);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
@@ -1294,6 +1346,19 @@ extern "C" int ser_openmax(const float* feats, const float* act_vec, const float
   if (B <= 0) return SER_OK;
   hipLaunchKernelGGL(openmax_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, (hipStream_t)stream, feats, act_vec, walpha, wbeta,
                      wtau, B, C, F, thresh, reduce, logits);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_dropout(const float* x, long long n, const void* state, unsigned site, float p, float* y, void* stream) {
+  SER_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%f out of range", p);
+  if (n <= 0) return SER_OK;
+  if (!state || p == 0.f) {
+    if (y != x) SER_CHECK_HIP(hipMemcpyAsync(y, x, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return SER_OK;
+  }
+  hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n,
+                     SerDropout{(const unsigned long long*)state, site, p}, y);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

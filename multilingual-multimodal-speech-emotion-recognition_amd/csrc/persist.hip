@@ -199,7 +199,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
                                                             float* __restrict__ Hs, float* __restrict__ X1,
                                                             float* __restrict__ U, float* __restrict__ A,
                                                             float* __restrict__ ST, int L, int M, int D, float eps,
-                                                            void* scratch) {
+                                                            void* scratch, SerDropout drop) {
   extern __shared__ float lds_dyn[];
   __shared__ float red[SW][64][4];
   __shared__ float st[16][4];
@@ -217,6 +217,11 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
   const unsigned tagbase = (*sc.launch + 1u) << 12;
   const long long slot_elems = (long long)16 * D;
   unsigned long long* dbg = g_stack_dbg;
+  // the two nn.Dropout layers of every block (ref classifier.py:83,85): site ids drop.site + 2 blk (+1)
+  const bool dropping = drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dstate = dropping ? *drop.state : 0ull;
+  const unsigned dthresh = ser_drop_thresh(drop.p);
+  const float dscale = 1.0f / (1.0f - drop.p);
   float4 b[4], bn[4];
   {
     const float* wr = tab[0].W1 + (long long)n * D + q * 4;
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
 #pragma unroll
         for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
         v = fmaxf(v + bv, 0.f);
+        if (dropping) v *= ser_drop_mult(dstate, drop.site + 2u * blk, (unsigned)(m * D + n), dthresh, dscale);
         st_ll(slot + m * D + n, v, tagbase + pA + 1);
         A[blk * MD + (long long)m * D + n] = v;
         x1v[r] = (panel[m * PD + n] - st[m][0]) * st[m][1] * g1n + b1n;
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(SW * 64) void stack_fwd_kernel(const StackBlockPtrs
 #pragma unroll
         for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
         v = v + bv;
+        if (dropping) v *= ser_drop_mult(dstate, drop.site + 2u * blk + 1u, (unsigned)(m * D + n), dthresh, dscale);
         v += x1v[r];
         if (blk + 1 < L) st_ll(slot + m * D + n, v, tagbase + pB + 1);
         Hs[blk * MD + (long long)m * D + n] = v;
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
                                                             const float* __restrict__ A, const float* __restrict__ ST,
                                                             float* __restrict__ DH, float* __restrict__ DA,
                                                             float* __restrict__ DU, float* __restrict__ DX1, int L, int M,
-                                                            int D, void* scratch) {
+                                                            int D, void* scratch, SerDropout drop, float* __restrict__ DT) {
   extern __shared__ float lds_dyn[];
   const int PD = D + PPAD;
   const float invD = 1.0f / (float)D;
@@ -420,9 +427,21 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
   const unsigned tagbase = (*sc.launch + 1u) << 12;
   const long long slot_elems = (long long)16 * D;
   unsigned long long* dbg = g_stack_dbg ? g_stack_dbg + 8 * 64 : nullptr;     // second half of the timeline buffer
+  // dropout: dh' reaches W2 through the second dropout of the block (mask regenerated), da carries the first one's
+  // scale; DT[i] = dropped dh' is kept for the batched weight gradients (dW2 = DT^T a)
+  const bool dropping = drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dstate = dropping ? *drop.state : 0ull;
+  const unsigned dthresh = ser_drop_thresh(drop.p);
+  const float dscale = 1.0f / (1.0f - drop.p);
   for (int idx = threadIdx.x; idx < M * nch4; idx += SW * 64) {
     const float4 v = ((const float4*)(DH + (long long)L * MD))[idx];
     *(float4*)(panel + (idx / nch4) * PD + (idx % nch4) * 4) = v;
+    if (dropping && blockIdx.x == 0) {
+      const unsigned e0 = (unsigned)idx * 4u, sid = drop.site + 2u * (L - 1) + 1u;
+      ((float4*)(DT + (long long)L * MD))[idx] =
+          make_float4(v.x * ser_drop_mult(dstate, sid, e0, dthresh, dscale), v.y * ser_drop_mult(dstate, sid, e0 + 1, dthresh, dscale),
+                      v.z * ser_drop_mult(dstate, sid, e0 + 2, dthresh, dscale), v.w * ser_drop_mult(dstate, sid, e0 + 3, dthresh, dscale));
+    }
   }
   float bw[16], bw2[16];
   {
@@ -471,7 +490,8 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int nn = (w + u * SW) * 4 + q;
-        const float av = (u < nit && nn < D) ? panel[ri * PD + min(nn, D - 1)] : 0.f;
+        float av = (u < nit && nn < D) ? panel[ri * PD + min(nn, D - 1)] : 0.f;
+        if (dropping) av *= ser_drop_mult(dstate, drop.site + 2u * blk + 1u, (unsigned)(ri * D + min(nn, D - 1)), dthresh, dscale);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[u], acc, 0, 0, 0);
       }
 #pragma unroll
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
         float v = 0.f;
 #pragma unroll
         for (int ww = 0; ww < SW; ++ww) v += red[ww][lane][r];
-        v = amask[r] > 0.f ? v : 0.f;
+        v = amask[r] > 0.f ? (dropping ? v * dscale : v) : 0.f;      // a > 0 <=> ReLU active and kept by the first dropout
         st_ll(slot + m * D + c, v, tagbase + p1 + 1);
         DA[blk * MD + (long long)m * D + c] = v;
       }
@@ -585,7 +605,15 @@ __global__ __launch_bounds__(SW * 64) void stack_bwd_kernel(const StackBlockPtrs
             o.z = r1 * (dgv[e].z - a1 - xh[e].z * a2);
             o.w = r1 * (dgv[e].w - a1 - xh[e].w * a2);
             *(float4*)(panel + row * PD + ch * 4) = o;
-            if ((ch >> 2) == (int)blockIdx.x) *(float4*)(DH + blk * MD + (long long)row * D + ch * 4) = o;
+            if ((ch >> 2) == (int)blockIdx.x) {
+              *(float4*)(DH + blk * MD + (long long)row * D + ch * 4) = o;
+              if (dropping && blk > 0) {                 // DH[blk] is the gradient at the output of block blk - 1
+                const unsigned e0 = (unsigned)(row * D + ch * 4), sid = drop.site + 2u * (blk - 1) + 1u;
+                *(float4*)(DT + blk * MD + (long long)row * D + ch * 4) =
+                    make_float4(o.x * ser_drop_mult(dstate, sid, e0, dthresh, dscale), o.y * ser_drop_mult(dstate, sid, e0 + 1, dthresh, dscale),
+                                o.z * ser_drop_mult(dstate, sid, e0 + 2, dthresh, dscale), o.w * ser_drop_mult(dstate, sid, e0 + 3, dthresh, dscale));
+              }
+            }
           }
         }
       }
@@ -664,23 +692,25 @@ extern "C" int ser_debug_stack_timeline(void* buf) {
 extern "C" size_t ser_stack_scratch_bytes(int D) { return 256 + (size_t)2 * 16 * D * sizeof(unsigned long long); }
 
 extern "C" int ser_stack_fwd(const void* ptr_table, const float* x0, float* Hs, float* X1, float* U, float* A, float* ST,
-                             int L, int M, int D, float eps, void* scratch, void* stream) {
+                             int L, int M, int D, float eps, void* scratch, const void* drop_state, unsigned drop_site,
+                             float drop_p, void* stream) {
   SER_TRY(stack_check(L, M, D));
   SER_REQUIRE(scratch != nullptr && ((uintptr_t)scratch & 255) == 0, "classifier stack: scratch must be 256-byte aligned");
   hipLaunchKernelGGL(stack_fwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)2 * 16 * (D + PPAD) * sizeof(float),
-                     (hipStream_t)stream, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, U, A, ST, L, M, D, eps, scratch);
+                     (hipStream_t)stream, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, U, A, ST, L, M, D, eps, scratch,
+                     SerDropout{(const unsigned long long*)drop_state, drop_site, drop_p});
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
 
 extern "C" int ser_stack_bwd(const void* ptr_table, const float* x0, const float* Hs, const float* X1, const float* A,
                              const float* ST, float* DH, float* DA, float* DU, float* DX1, int L, int M, int D, void* scratch,
-                             void* stream) {
+                             const void* drop_state, unsigned drop_site, float drop_p, float* DT, void* stream) {
   SER_TRY(stack_check(L, M, D));
   SER_REQUIRE(scratch != nullptr && ((uintptr_t)scratch & 255) == 0, "classifier stack: scratch must be 256-byte aligned");
   hipLaunchKernelGGL(stack_bwd_kernel, dim3(D / 16), dim3(SW * 64), (size_t)(2 * 16 * (D + PPAD) + 2 * 16 * D + 2 * D) * sizeof(float),
                      (hipStream_t)stream, (const StackBlockPtrs*)ptr_table, x0, Hs, X1, A, ST, DH, DA, DU, DX1, L, M, D,
-                     scratch);
+                     scratch, SerDropout{(const unsigned long long*)drop_state, drop_site, drop_p}, DT);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

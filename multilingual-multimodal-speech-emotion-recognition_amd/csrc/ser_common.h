@@ -127,6 +127,26 @@ SER_DEVFN float wave_max(float v) {
   return fmaxf(fmaxf(lane_value(v, 0), lane_value(v, 16)), fmaxf(lane_value(v, 32), lane_value(v, 48)));
 }
 
+// ---- dropout masks: a counter-based generator keyed by (state, site, element).  `state` lives in device memory (so a
+// captured graph draws new masks at every replay) and is advanced by the host side once per training step; `site` names
+// the dropout layer; backward regenerates the mask from the same triple instead of storing it.
+SER_DEVFN unsigned ser_mix32(unsigned h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+struct SerDropout {
+  const unsigned long long* state;   // null or p == 0: identity
+  unsigned site;
+  float p;
+};
+// multiplier of element idx: 1 / (1 - p) with probability 1 - p, else 0
+SER_DEVFN float ser_drop_mult(unsigned long long st, unsigned site, unsigned idx, unsigned thresh, float scale) {
+  unsigned h = ser_mix32(idx * 0x9E3779B1u ^ (unsigned)st);
+  h = ser_mix32(h + site * 0x85EBCA77u + (unsigned)(st >> 32));
+  return h >= thresh ? scale : 0.f;
+}
+SER_DEVFN unsigned ser_drop_thresh(float p) { return (unsigned)fminf(p * 4294967296.0f, 4294967040.0f); }
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // simple bump allocator over a caller-provided workspace

@@ -72,6 +72,9 @@ class _ClassifierFn(torch.autograd.Function):
         t0 = O.linear_fwd(x, ip[0].weight, ip[0].bias)
         y0, ln0 = O.ln_fwd(t0, ip[1].weight, ip[1].bias)
         h = O.act_fwd(y0, O.ACT_RELU)
+        sites = m._drop_sites
+        d_in, d_out, d_unc = O.dropout_ctx(ip[3].p), O.dropout_ctx(op[3].p), O.dropout_ctx(uh_[2].p)
+        O.dropout_(h, d_in, sites[0])                            # ref classifier.py:109
         h0 = h
         blocks = []
         stack = None
@@ -79,8 +82,9 @@ class _ClassifierFn(torch.autograd.Function):
         if nblk and O.stack_supported(nblk, h.shape[0], h.shape[1]):
             # the whole residual stack in one persistent launch
             tab, _, flags = m._stack_tables()
-            Hs, X1, U, A, ST = O.stack_fwd(h, tab, nblk, flags[0], dc.layer_norms[0].eps)
-            stack = (Hs, X1, U, A, ST)
+            d_blk = O.dropout_ctx(dc.residual_layers[0].block[3].p)             # ref classifier.py:83,85
+            Hs, X1, U, A, ST = O.stack_fwd(h, tab, nblk, flags[0], dc.layer_norms[0].eps, d_blk, sites[3])
+            stack = (Hs, X1, U, A, ST, d_blk)
             h = Hs[nblk - 1]
         fused_ln = h.shape[1] <= 512
         for blk, lno in (() if stack is not None else zip(dc.residual_layers, dc.layer_norms)):
@@ -100,16 +104,27 @@ class _ClassifierFn(torch.autograd.Function):
                 u, lnB = O.ln_fwd(x1, b[0].weight, b[0].bias)
                 stats = None
                 a = O.linear_fwd(u, b[1].weight, b[1].bias, O.ACT_RELU)
-            h = O.linear_fwd(a, b[4].weight, b[4].bias, residual=x1)
-            blocks.append((lnA, lnB, u, a, hin, x1, stats))
+            d_b = O.dropout_ctx(b[3].p)                            # per-Linear path (M > 16): standalone dropout launches
+            if d_b is None:
+                h = O.linear_fwd(a, b[4].weight, b[4].bias, residual=x1)
+            else:
+                bi = len(blocks)
+                O.dropout_(a, d_b, sites[3] + 2 * bi)
+                h = O.linear_fwd(a, b[4].weight, b[4].bias)
+                O.dropout_(h, d_b, sites[3] + 2 * bi + 1)
+                O.axpby(x1, h, 1.0, 1.0)                         # h = x1 + drop(t)
+            blocks.append((lnA, lnB, u, a, hin, x1, stats, d_b))
         tf = O.linear_fwd(h, op[0].weight, op[0].bias)
         yf, lnF = O.ln_fwd(tf, op[1].weight, op[1].bias)
         f = O.act_fwd(yf, O.ACT_RELU)
+        O.dropout_(f, d_out, sites[1])                           # ref classifier.py:127,218
         logits = O.linear_fwd(f, op[4].weight, op[4].bias)
         uh = O.linear_fwd(f, uh_[0].weight, uh_[0].bias, O.ACT_RELU)
+        O.dropout_(uh, d_unc, sites[2])                          # ref classifier.py:195
         unc = O.linear_fwd(uh, uh_[3].weight, uh_[3].bias, O.ACT_SIGMOID)
         ctx.m = m
         ctx.saved = (x, ln0, h0, blocks, h, lnF, f, uh, unc, stack)
+        ctx.drop = (d_in, d_out, d_unc)
         ctx.need_dx = x.requires_grad
         ctx.mark_non_differentiable(f)
         return logits, unc, f
@@ -120,6 +135,8 @@ class _ClassifierFn(torch.autograd.Function):
         dc, uh_ = m.deep_classifier, m.uncertainty_head
         ip, op = dc.input_projection, dc.output_projection
         x, ln0, h0, blocks, h_last, lnF, f, uh, unc, stack = ctx.saved
+        d_in, d_out, d_unc = ctx.drop
+        sites = m._drop_sites
         fp = m._flat
         acc = fp.accumulating()
         g = fp.gview
@@ -136,25 +153,28 @@ class _ClassifierFn(torch.autograd.Function):
         du2 = O.act_bwd(dunc, unc, O.ACT_SIGMOID, inplace=False)
         O.linear_wgrad(du2, uh, g(uh_[3].weight), g(uh_[3].bias), acc)
         duh = O.linear_dgrad(du2, uh_[3].weight)
+        O.dropout_(duh, d_unc, sites[2])
         O.act_bwd(duh, uh, O.ACT_RELU)
         O.linear_wgrad(duh, f, g(uh_[0].weight), g(uh_[0].bias), acc)
         O.linear_dgrad(duh, uh_[0].weight, out=df, accumulate=True)
         # output projection
+        O.dropout_(df, d_out, sites[1])
         O.act_bwd(df, f, O.ACT_RELU)
         dtf = O.ln_bwd(df, lnF, op[1].weight, g(op[1].weight), g(op[1].bias), acc)
         O.linear_wgrad(dtf, h_last, g(op[0].weight), g(op[0].bias), acc)
         wg = []
         if stack is not None:
-            Hs, X1, U, A, ST = stack
+            Hs, X1, U, A, ST, d_blk = stack
             nblk, Mr, Dd = Hs.shape
             tab, gtab, flags = m._stack_tables()
             DH = torch.empty(nblk + 1, Mr, Dd, dtype=torch.float32, device=dev)
             O.linear_dgrad(dtf, op[0].weight, out=DH[nblk])
-            DA, DU, DX1 = O.stack_bwd(tab, h0, Hs, X1, A, ST, DH, flags[1])
+            DA, DU, DX1, DT = O.stack_bwd(tab, h0, Hs, X1, A, ST, DH, flags[1], d_blk, sites[3])
             O.stack_ln_param_bwd(gtab, h0, Hs, X1, ST, DU, DX1, acc)
+            Gout = DT if DT is not None else DH          # gradient at the (dropped) second Linear's output
             for i in range(nblk - 1, -1, -1):
                 b = dc.residual_layers[i].block
-                wg.append((DH[i + 1], A[i], g(b[4].weight), g(b[4].bias)))
+                wg.append((Gout[i + 1], A[i], g(b[4].weight), g(b[4].bias)))
                 wg.append((DA[i], U[i], g(b[1].weight), g(b[1].bias)))
             dh = DH[0]
         else:
@@ -162,10 +182,14 @@ class _ClassifierFn(torch.autograd.Function):
         # residual stack, last block first.  The weight gradients are only collected here and issued in ONE batched
         # launch after the loop: they are off the dgrad chain, which is the critical path of this backward.
         for i in range(len(blocks) - 1, -1, -1):
-            lnA, lnB, u, a, hin, x1, stats = blocks[i]
+            lnA, lnB, u, a, hin, x1, stats, d_b = blocks[i]
             b, lno = dc.residual_layers[i].block, dc.layer_norms[i]
-            da = O.linear_dgrad(dh, b[4].weight, relu_mask=a)              # dgrad with ReLU' fused
-            wg.append((dh, a, g(b[4].weight), g(b[4].bias)))
+            dt = dh
+            if d_b is not None:                                            # gradient through the second dropout
+                dt = O.dropout_(dh.clone(), d_b, sites[3] + 2 * i + 1)
+            da = O.linear_dgrad(dt, b[4].weight, relu_mask=a)              # dgrad with ReLU' fused (a > 0: active and kept)
+            O.dropout_(da, d_b, sites[3] + 2 * i)                          # the first dropout's 1 / (1 - p) on the kept entries
+            wg.append((dt, a, g(b[4].weight), g(b[4].bias)))
             wg.append((da, u, g(b[1].weight), g(b[1].bias)))
             du = O.linear_dgrad(da, b[1].weight)
             if stats is not None:
@@ -177,6 +201,7 @@ class _ClassifierFn(torch.autograd.Function):
         if wg:
             O.linear_wgrad_batch(wg, acc)
         # input projection
+        O.dropout_(dh, d_in, sites[0])
         O.act_bwd(dh, h0, O.ACT_RELU)
         dt0 = O.ln_bwd(dh, ln0, ip[1].weight, g(ip[1].weight), g(ip[1].bias), acc)
         O.linear_wgrad(dt0, x, g(ip[0].weight), g(ip[0].bias), acc)
@@ -209,6 +234,8 @@ class AdvancedOpenMaxClassifier(nn.Module):
         grad_params = (list(self.deep_classifier.parameters()) + self._anchor_params +
                        list(self.uncertainty_head.parameters()))       # anchor `temperature` never gets a gradient
         self._flat = FlatParams(grad_params)
+        # input projection, output projection, uncertainty head, then two per residual block (first id of the run)
+        self._drop_sites = (O.new_dropout_site(), O.new_dropout_site(), O.new_dropout_site(), O.new_dropout_site(2 * num_layers))
 
     def _run(self, x):
         self._flat.ensure()

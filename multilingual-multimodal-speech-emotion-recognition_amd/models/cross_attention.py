@@ -3,8 +3,9 @@
 Same constructor, attributes and state_dict keys (q_a, k_t, v_t, attn_a.{in_proj_weight,in_proj_bias,
 out_proj.*}, out_a, q_t, k_a, v_a, attn_t.*, out_t, norm_a, norm_t).  `attn_a` / `attn_t` stay
 nn.MultiheadAttention objects so that checkpoints interchange, but they are never called: the
-projections run on the fp32 MFMA GEMM and softmax(QK^T)V on the xattn kernels.  Dropout follows the
-parity definition of the build (identity).
+projections run on the fp32 MFMA GEMM and softmax(QK^T)V on the xattn kernels.  Dropout (attention
+probabilities and block outputs) is active inside `_ops.dropout_scope` (training steps of SERSystem) and
+the identity otherwise, which is the parity definition of the build.
 """
 from typing import Optional
 
@@ -25,7 +26,7 @@ def _side_stream():
     return _SIDE[dev]
 
 
-def _dir_fwd(x_q, x_kv, kv_mask, B, Sq, Sk, Wq, bq, Wk, bk, Wv, bv, Wi, bi, Wo, bo, Wout, bout, ng, nb, heads):
+def _dir_fwd(x_q, x_kv, kv_mask, B, Sq, Sk, Wq, bq, Wk, bk, Wv, bv, Wi, bi, Wo, bo, Wout, bout, ng, nb, heads, p_out=0.0, site=0, p_attn=0.0, site_attn=0):
     E = Wq.shape[0]
     q1 = O.linear_fwd(x_q, Wq, bq)
     k1 = O.linear_fwd(x_kv, Wk, bk)
@@ -33,24 +34,28 @@ def _dir_fwd(x_q, x_kv, kv_mask, B, Sq, Sk, Wq, bq, Wk, bk, Wv, bv, Wi, bi, Wo, 
     Q = O.linear_fwd(q1, Wi[:E], bi[:E])
     K = O.linear_fwd(k1, Wi[E:2 * E], bi[E:2 * E])
     V = O.linear_fwd(v1, Wi[2 * E:], bi[2 * E:])
-    ctx, P = O.xattn_fwd(Q, K, V, kv_mask, B, Sq, Sk, heads)
+    dattn = O.dropout_ctx(p_attn)                               # nn.MultiheadAttention(dropout=p), ref cross_attention.py:18,25
+    ctx, P = O.xattn_fwd(Q, K, V, kv_mask, B, Sq, Sk, heads, dattn, site_attn)
     c2 = O.linear_fwd(ctx, Wo, bo)
     o = O.linear_fwd(c2, Wout, bout)
+    dout = O.dropout_ctx(p_out)                                  # ref cross_attention.py:43,51: self.dropout(out)
+    O.dropout_(o, dout, site)
     y, ln = O.ln_fwd(x_q, ng, nb, 1e-5, x2=o)
-    return y, (q1, k1, v1, Q, K, V, P, ctx, c2, ln)
+    return y, (q1, k1, v1, Q, K, V, P, ctx, c2, ln, dout, site, dattn, site_attn)
 
 
 def _dir_bwd(dy, saved, x_q, x_kv, B, Sq, Sk, Wq, Wk, Wv, Wi, Wo, Wout, ng, g, acc, heads, dx_q, dx_kv):
     """Accumulates input gradients into dx_q / dx_kv (already initialised) and writes parameter grads via g(param)."""
-    q1, k1, v1, Q, K, V, P, ctx, c2, ln = saved
+    q1, k1, v1, Q, K, V, P, ctx, c2, ln, dout, site, dattn, site_attn = saved
     E = Wq["w"].shape[0]
     dz = O.ln_bwd(dy, ln, ng["w"], g(ng["w"]), g(ng["b"]), acc)
     O.axpby(dz, dx_q, 1.0, 1.0)                                  # residual branch
+    O.dropout_(dz, dout, site)                                   # from here on dz is the gradient at the dropped branch
     O.linear_wgrad(dz, c2, g(Wout["w"]), g(Wout["b"]), acc)
     dc2 = O.linear_dgrad(dz, Wout["w"])
     O.linear_wgrad(dc2, ctx, g(Wo["w"]), g(Wo["b"]), acc)
     dctx = O.linear_dgrad(dc2, Wo["w"])
-    dQ, dK, dV = O.xattn_bwd(dctx, Q, K, V, P, B, Sq, Sk, heads)
+    dQ, dK, dV = O.xattn_bwd(dctx, Q, K, V, P, B, Sq, Sk, heads, dattn, site_attn)
     gWi, gbi = g(Wi["w"]), g(Wi["b"])
     O.linear_wgrad(dQ, q1, gWi[:E], gbi[:E], acc)
     O.linear_wgrad(dK, k1, gWi[E:2 * E], gbi[E:2 * E], acc)
@@ -79,12 +84,13 @@ class _CrossFn(torch.autograd.Function):
         side.wait_stream(cur)
         ya, sa = _dir_fwd(a2, t2, tm, B, Sa, St, m.q_a.weight, m.q_a.bias, m.k_t.weight, m.k_t.bias, m.v_t.weight,
                           m.v_t.bias, m.attn_a.in_proj_weight, m.attn_a.in_proj_bias, m.attn_a.out_proj.weight,
-                          m.attn_a.out_proj.bias, m.out_a.weight, m.out_a.bias, m.norm_a.weight, m.norm_a.bias, m.num_heads)
+                          m.attn_a.out_proj.bias, m.out_a.weight, m.out_a.bias, m.norm_a.weight, m.norm_a.bias, m.num_heads,
+                          m.dropout.p, m._drop_sites[0], m.attn_a.dropout, m._drop_sites[2])
         with torch.cuda.stream(side):     # T <- A is independent of A <- T
             yt, st = _dir_fwd(t2, a2, am, B, St, Sa, m.q_t.weight, m.q_t.bias, m.k_a.weight, m.k_a.bias, m.v_a.weight,
                               m.v_a.bias, m.attn_t.in_proj_weight, m.attn_t.in_proj_bias, m.attn_t.out_proj.weight,
                               m.attn_t.out_proj.bias, m.out_t.weight, m.out_t.bias, m.norm_t.weight, m.norm_t.bias,
-                              m.num_heads)
+                              m.num_heads, m.dropout.p, m._drop_sites[1], m.attn_t.dropout, m._drop_sites[3])
         cur.wait_stream(side)
         for tns in (a2, t2):
             tns.record_stream(side)
@@ -146,6 +152,7 @@ class CrossModalAttention(nn.Module):
         self.norm_a = nn.LayerNorm(audio_dim)
         self.norm_t = nn.LayerNorm(text_dim)
         self._flat = FlatParams(list(self.parameters()))
+        self._drop_sites = tuple(O.new_dropout_site() for _ in range(4))   # output a, output t, attention a, attention t
 
     def forward(self, audio_seq: torch.Tensor, text_seq: torch.Tensor, audio_mask: Optional[torch.Tensor] = None,
                 text_mask: Optional[torch.Tensor] = None):

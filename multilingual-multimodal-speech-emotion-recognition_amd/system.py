@@ -42,6 +42,18 @@ class SERSystem(nn.Module):
         # per multiply, fp32 accumulation), as the frozen encoders do; `bf16x3` keeps the fp32-equivalent 3-product
         # form everywhere.  Forward products of the head always use the 3-product form (1e-3 logit budget).
         self.head_backward_products = 1 if getattr(audio_encoder, "precision", "bf16x3") == "bf16" else 3
+        # Dropout of the trainable head in training mode (cross-attention, fusion, classifier: the nn.Dropout layers of the
+        # reference).  The masks come from a counter-based generator keyed by (state, layer, element); `state` is a device
+        # word advanced once per training step (inside the captured graph), so every replay draws new masks.  Parity with
+        # the reference's golden vectors is defined with dropout off (`train_dropout = False`, or `.eval()`).
+        self.train_dropout = True
+        self.dropout_seed = 0x5EED
+        self._drop_state = None
+        nl = num_layers
+        self.cross._drop_sites = (1, 2, 3, 4)
+        self.fusion._drop_sites = (5, 6)
+        self.classifier._drop_sites = (7, 8, 9, 16)               # 16 .. 16 + 2 * num_layers - 1: the residual blocks
+        assert 16 + 2 * nl < 1 << 16
 
     # ---- reference checkpoint layout (train.py:249-262) ---------------------------------------------------------
     CKPT_KEYS = ("audio_encoder", "text_encoder", "cross", "pool_a", "pool_t", "fusion", "classifier", "prototypes")
@@ -102,6 +114,17 @@ class SERSystem(nn.Module):
         from . import _lib as L
         L.check(L.lib.ser_set_head_backward_products(self.head_backward_products), "ser_set_head_backward_products")
 
+    def _dropout_scope(self):
+        """Context for the training forward: dropout on (and the generator state advanced by one step) when the system
+        is in training mode with `train_dropout`; otherwise the identity."""
+        if not (self.training and self.train_dropout):
+            return _ops.dropout_scope(None)
+        dev = next(self.classifier.parameters()).device
+        if self._drop_state is None or self._drop_state.device != dev:
+            self._drop_state = torch.full((1,), int(self.dropout_seed), dtype=torch.int64, device=dev)
+        self._drop_state.add_(1)                                  # one launch; captured with the step, so replays advance it
+        return _ops.dropout_scope(self._drop_state)
+
     def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True):
         """Everything trainable: adapters -> cross-attention -> pooling -> fusion -> classifier -> loss."""
         from .models.adapter import adapter_apply
@@ -110,15 +133,16 @@ class SERSystem(nn.Module):
         if self._side is None:
             self._side = torch.cuda.Stream()
         side = self._side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            t_seq = adapter_apply(self.text_encoder, t_enc)
-        a_seq = adapter_apply(self.audio_encoder, a_enc)
-        cur.wait_stream(side)
-        t_seq.record_stream(cur)
-        a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
-        fused = self.head(a_seq, a_mask, t_seq, attn_mask.to(torch.float32))
-        logits, unc, _ = self.classifier(fused, use_openmax=False, return_uncertainty=True)
+        with self._dropout_scope():
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                t_seq = adapter_apply(self.text_encoder, t_enc)
+            a_seq = adapter_apply(self.audio_encoder, a_enc)
+            cur.wait_stream(side)
+            t_seq.record_stream(cur)
+            a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
+            fused = self.head(a_seq, a_mask, t_seq, attn_mask.to(torch.float32))
+            logits, unc, _ = self.classifier(fused, use_openmax=False, return_uncertainty=True)
         total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)
         return total, logits
 
@@ -145,8 +169,9 @@ class SERSystem(nn.Module):
 
     def loss(self, wave, ids, attn_mask, labels, use_proto=True):
         self._set_precision()
-        fused = self.head(*self.encode(wave, ids, attn_mask))
-        logits, unc, anchor = self.classifier(fused, use_openmax=False, return_uncertainty=True)
+        with self._dropout_scope():
+            fused = self.head(*self.encode(wave, ids, attn_mask))
+            logits, unc, anchor = self.classifier(fused, use_openmax=False, return_uncertainty=True)
         total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)
         return total, logits
 
