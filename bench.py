@@ -228,7 +228,8 @@ def main():
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
                        "schedule": "frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "
                                    "(two streams; one encoder pass and one update per step)" if pipeline else "sequential",
-                       "stress_sizes": bool(args.stress)},
+                       "stress_sizes": bool(args.stress),
+                       "head_dropout": "training mode (77 nn.Dropout sites active; frozen encoders in eval semantics)"},
             "roofline": roof, "cpu_baseline": cpu,
             "logit_max_abs_err_vs_cpu_oracle": err, "class_indices_equal": same,
             "whole_step_algorithmic_tflops": None if step_tflops is None else round(step_tflops, 2),
