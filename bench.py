@@ -134,6 +134,7 @@ def main():
     if os.environ.get("SER_GEMM_PERSIST"):
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
     sysm, wc, xc = build_system(args.precision, dev, stress=args.stress)
+    sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
     sysm.train()
     opt = sysm.make_optimizer(lr=1e-4)
     reducer = GradReducer(sysm) if world > 1 else None

@@ -121,6 +121,7 @@ def main(argv=None):
     ae = AudioEncoder(args.audio_model, use_quality_gates=False, use_audio_conditioning=False, precision=args.precision)
     te = TextEncoder(args.text_model, precision=args.precision)
     sysm = SERSystem(ae, te, num_labels=args.num_labels).to(device)
+    sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
     opt = sysm.make_optimizer(lr=args.lr)
     total_steps = len(train_loader) * args.epochs
     sched = WarmupCosine(opt, total_steps, args.warmup_ratio)
