@@ -144,6 +144,25 @@ def test_fusion_and_cross_attention_gradients_are_consistent_under_dropout(OP):
     _directional_check(f_cr, [a, t])
 
 
+def test_classifier_gradients_consistent_under_dropout_on_both_paths(OP):
+    """Directional-derivative check of the whole classifier under a fixed mask: the persistent stack (M <= 16) and the
+    launch-per-Linear path that larger batches take (M = 24 here)."""
+    from ser_amd.models.classifier import AdvancedOpenMaxClassifier
+    torch.manual_seed(3)
+    st = _state(17)
+    for rows in (8, 24):
+        m = AdvancedOpenMaxClassifier(input_dim=64, num_labels=4, num_layers=2, base_dim=64, dropout=0.2).cuda().train()
+        x = torch.randn(rows, 64, device="cuda", requires_grad=True)
+        wl, wu = torch.randn(rows, 4, device="cuda"), torch.randn(rows, 1, device="cuda")
+        assert OP.stack_supported(2, rows, 64) == (rows <= 16)
+
+        def f():
+            with OP.dropout_scope(st):
+                logits, unc, _ = m(x, use_openmax=False, return_uncertainty=True)
+            return (logits * wl).sum() + (unc * wu).sum()
+        _directional_check(f, [x] + [p for p in m.deep_classifier.parameters()][:6], rel=5e-2)
+
+
 def test_system_dropout_is_deterministic_and_replays_draw_new_masks():
     import __graft_entry__ as ge
     from ser_amd.system import TrainStepper
