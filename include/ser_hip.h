@@ -280,13 +280,14 @@ int ser_scale_dev(float* x, const float* s, long long n, void* stream);         
  * torch nn/functional.py multi_head_attention_forward).  P [B,heads,Sq,Sk] is kept for backward. */
 int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* key_mask, int B,
                   int Sq, int Sk, int heads, int head_dim, float* P, float* ctx, int ldc, const void* drop_state,
-                  unsigned drop_site, float drop_p, void* stream);
+                  unsigned drop_site, float drop_p, float* P_dropped, void* stream);
 /* drop_*: nn.MultiheadAttention's attention dropout in training mode (ctx = (P * m / (1 - p)) v; P as stored is the
- * softmax output; see ser_dropout for the generator; NULL state or p = 0: identity). */
+ * softmax output and P_dropped [B, heads, Sq, Sk] receives P * m / (1 - p) for dv in backward; see ser_dropout for the
+ * generator; NULL state or p = 0: identity, P_dropped may be NULL). */
 int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                   const float* P, int B, int Sq, int Sk, int heads, int head_dim, float* dS, float* dq, int lddq,
                   float* dk, int lddk, float* dv, int lddv, const void* drop_state, unsigned drop_site, float drop_p,
-                  void* stream);
+                  const float* P_dropped, void* stream);
 
 /* AttentiveStatsPooling core (pooling.py:21-28): masked softmax over time of `logits`, weighted
  * mean and std -> out [B,2D]; alpha [B,S] kept for backward. */

@@ -193,8 +193,8 @@ _sig("ser_act_fwd", i32, vp, i32, i64, vp, vp)
 _sig("ser_act_bwd", i32, vp, vp, i32, i64, vp, vp)
 _sig("ser_axpby", i32, vp, f32, f32, i64, vp, vp)
 _sig("ser_scale_dev", i32, vp, vp, i64, vp)
-_sig("ser_xattn_fwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, C.c_uint, f32, vp)
-_sig("ser_xattn_bwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, C.c_uint, f32, vp)
+_sig("ser_xattn_fwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, C.c_uint, f32, vp, vp)
+_sig("ser_xattn_bwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, vp, C.c_uint, f32, vp, vp)
 _sig("ser_pool_fwd", i32, vp, vp, vp, i32, i32, i32, vp, vp, vp)
 _sig("ser_pool_bwd", i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp)
 _sig("ser_fusion_mix_fwd", i32, vp, vp, vp, vp, i32, i32, vp, vp)

@@ -305,13 +305,16 @@ def xattn_fwd(q, k, v, key_mask, B, Sq, Sk, heads, dctx=None, site=0):
     P = empty(B, heads, Sq, Sk, like=q)
     ctx = empty(B * Sq, E, like=q)
     state, p = dctx if dctx is not None else (None, 0.0)
+    Pd = torch.empty_like(P) if dctx is not None else None          # dropped probabilities (dv in backward)
     L.check(L.lib.ser_xattn_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
                                 L.ptr(key_mask), B, Sq, Sk, heads, hd, L.ptr(P), L.ptr(ctx), E, L.ptr(state), int(site), p,
-                                L.stream_ptr()), "ser_xattn_fwd")
-    return ctx, P
+                                L.ptr(Pd), L.stream_ptr()), "ser_xattn_fwd")
+    return ctx, (P if Pd is None else (P, Pd))
 
 
 def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads, drop=None, site=0):
+    """P: what xattn_fwd returned (the softmax output, or (softmax, dropped) with dropout)."""
+    P, Pd = P if isinstance(P, tuple) else (P, None)
     E = q.shape[1]
     hd = E // heads
     dS = torch.empty_like(P)
@@ -319,7 +322,7 @@ def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads, drop=None, site=0):
     L.check(L.lib.ser_xattn_bwd(L.ptr(dctx), E, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
                                 v.stride(0), L.ptr(P), B, Sq, Sk, heads, hd, L.ptr(dS), L.ptr(dq), E, L.ptr(dk), E, L.ptr(dv),
                                 E, L.ptr(drop[0] if drop is not None else None), int(site), drop[1] if drop is not None else 0.0,
-                                L.stream_ptr()), "ser_xattn_bwd")
+                                L.ptr(Pd), L.stream_ptr()), "ser_xattn_bwd")
     return dq, dk, dv
 
 

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
                                                         int ldk, const float* __restrict__ v, int ldv,
                                                         const float* __restrict__ kmask, int B, int Sq, int Sk, int heads,
                                                         int hd, float* __restrict__ P, float* __restrict__ ctx, int ldc,
-                                                        SerDropout drop) {
+                                                        SerDropout drop, float* __restrict__ Pd) {
   __shared__ float ps[4][XA_MAXK];
   const XDrop xd = xdrop_init(drop);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const float* __restrict_
     const float p = ps[w][j] * inv;
     ps[w][j] = p * xdrop_mult(xd, prow0 + j);
     Pr[j] = p;
+    if (Pd) Pd[prow0 + j] = ps[w][j];                 // dropped probabilities, for dv in backward
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -512,9 +513,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
                                                            const float* __restrict__ q, int ldq,
                                                            const float* __restrict__ P, const float* __restrict__ dS,
                                                            int B, int Sq, int Sk, int heads, int hd,
-                                                           float* __restrict__ dk, int ldk, float* __restrict__ dv, int ldv,
-                                                           SerDropout drop) {
-  const XDrop xd = xdrop_init(drop);
+                                                           float* __restrict__ dk, int ldk, float* __restrict__ dv, int ldv) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long long row = (long long)blockIdx.x * 4 + w;   // over B*heads*Sk
   if (row >= (long long)B * heads * Sk) return;
@@ -531,7 +530,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
     if (d < hd) {
       float acc = 0.f;
       for (int i = 0; i < Sq; ++i) {
-        const float wgt = isv ? Pc[(long long)i * Sk] * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j) : Sc[(long long)i * Sk];
+        const float wgt = isv ? Pc[(long long)i * Sk] : Sc[(long long)i * Sk];
         const float* src = isv ? dctx + ((long long)b * Sq + i) * ldc : q + ((long long)b * Sq + i) * ldq;
         acc = fmaf(wgt, src[h * hd + d], acc);
       }
@@ -542,8 +541,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
     float ak = 0.f, av = 0.f;
     for (int i = 0; i < Sq; ++i) {
       ak = fmaf(Sc[(long long)i * Sk], q[((long long)b * Sq + i) * ldq + h * hd + lane], ak);
-      av = fmaf(Pc[(long long)i * Sk] * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j),
-                dctx[((long long)b * Sq + i) * ldc + h * hd + lane], av);
+      av = fmaf(Pc[(long long)i * Sk], dctx[((long long)b * Sq + i) * ldc + h * hd + lane], av);
     }
     dk[((long long)b * Sk + j) * ldk + h * hd + lane] = ak * scale;
     dv[((long long)b * Sk + j) * ldv + h * hd + lane] = av;
@@ -564,7 +562,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __rest
                                                              int ldk, const float* __restrict__ v, int ldv,
                                                              const float* __restrict__ kmask, int Sq, int Sk, int heads,
                                                              float* __restrict__ P, float* __restrict__ ctx, int ldc,
-                                                             SerDropout drop) {
+                                                             SerDropout drop, float* __restrict__ Pd) {
   const XDrop xd = xdrop_init(drop);
   __shared__ float Kt[XF_HD][XF_LD];       // K^T: [d][key]
   __shared__ float Vs[XF_MAXS][XF_HD];     // V:   [key][d]
@@ -615,6 +613,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __rest
         const float p = sc[u] * inv;
         prow[w][j] = p * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + j);
         Pr[j] = p;
+        if (Pd) Pd[(((long long)b * heads + h) * Sq + i) * Sk + j] = prow[w][j];
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -694,8 +693,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __re
 __global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ q,
                                                                 int ldq, const float* __restrict__ P, const float* __restrict__ dS,
                                                                 int Sq, int Sk, int heads, float* __restrict__ dk, int ldk,
-                                                                float* __restrict__ dv, int ldv, SerDropout drop) {
-  const XDrop xd = xdrop_init(drop);
+                                                                float* __restrict__ dv, int ldv) {
   __shared__ float Qs[XF_MAXS][XF_HD];
   __shared__ float Ds[XF_MAXS][XF_HD];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -714,8 +712,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __r
   for (int e = 0; e < 8; ++e) ak[e] = av[e] = 0.f;
   const int jj = j < Sk ? j : Sk - 1;
   for (int i = 0; i < Sq; ++i) {
-    const float p = Pc[(long long)i * Sk + jj] * xdrop_mult(xd, (((long long)b * heads + h) * Sq + i) * Sk + jj);
-    const float s = Sc[(long long)i * Sk + jj];                                      // coalesced over the 64 keys
+    const float p = Pc[(long long)i * Sk + jj], s = Sc[(long long)i * Sk + jj];     // coalesced over the 64 keys
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       ak[e] = fmaf(s, Qs[i][w * 8 + e], ak[e]);       // LDS broadcast reads
@@ -1246,20 +1243,21 @@ extern "C" int ser_axpby(const float* x, float a, float b, long long n, float* y
 
 extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                              const float* key_mask, int B, int Sq, int Sk, int heads, int head_dim, float* P, float* ctx,
-                             int ldc, const void* drop_state, unsigned drop_site, float drop_p, void* stream) {
+                             int ldc, const void* drop_state, unsigned drop_site, float drop_p, float* P_dropped, void* stream) {
   SER_REQUIRE(Sk <= XA_MAXK && head_dim <= 64 && head_dim > 0, "xattn: Sk=%d (max %d) head_dim=%d (max 64)", Sk, XA_MAXK, head_dim);
   SER_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "xattn: dropout p=%f out of range", drop_p);
+  SER_REQUIRE(!(drop_state && drop_p > 0.f) || P_dropped, "xattn: dropout needs the P_dropped output");
   const long long rows = (long long)B * heads * Sq;
   if (rows <= 0) return SER_OK;
   const SerDropout drop{(const unsigned long long*)drop_state, drop_site, drop_p};
   if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
     hipLaunchKernelGGL(xattn_fwd_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
-                       v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc, drop);
+                       v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc, drop, P_dropped);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
   hipLaunchKernelGGL(xattn_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk, v,
-                     ldv, key_mask, B, Sq, Sk, heads, head_dim, P, ctx, ldc, drop);
+                     ldv, key_mask, B, Sq, Sk, heads, head_dim, P, ctx, ldc, drop, P_dropped);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
@@ -1267,24 +1265,27 @@ extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, c
 extern "C" int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk, const float* v,
                              int ldv, const float* P, int B, int Sq, int Sk, int heads, int head_dim, float* dS,
                              float* dq, int lddq, float* dk, int lddk, float* dv, int lddv, const void* drop_state,
-                             unsigned drop_site, float drop_p, void* stream) {
+                             unsigned drop_site, float drop_p, const float* P_dropped, void* stream) {
   SER_REQUIRE(Sk <= XA_MAXK && head_dim <= 64 && head_dim > 0, "xattn_bwd: Sk=%d head_dim=%d unsupported", Sk, head_dim);
   hipStream_t st = (hipStream_t)stream;
   const long long rq = (long long)B * heads * Sq, rk = (long long)B * heads * Sk;
   if (rq <= 0 || rk <= 0) return SER_OK;
   const SerDropout drop{(const unsigned long long*)drop_state, drop_site, drop_p};
+  const bool dropping = drop_state && drop_p > 0.f;
+  SER_REQUIRE(!dropping || P_dropped, "xattn_bwd: dropout needs P_dropped from the forward call");
+  const float* Pv = dropping ? P_dropped : P;       // weights of dv = Pv^T dctx
   if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
     hipLaunchKernelGGL(xattn_bwd_q_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
                        Sq, Sk, heads, dS, dq, lddq, drop);
-    hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, P, dS, Sq,
-                       Sk, heads, dk, lddk, dv, lddv, drop);
+    hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, Pv, dS, Sq,
+                       Sk, heads, dk, lddk, dv, lddv);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
   hipLaunchKernelGGL(xattn_bwd_q_kernel, dim3((unsigned)((rq + 3) / 4)), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P, B, Sq,
                      Sk, heads, head_dim, dS, dq, lddq, drop);
-  hipLaunchKernelGGL(xattn_bwd_kv_kernel, dim3((unsigned)((rk + 3) / 4)), dim3(256), 0, st, dctx, ldc, q, ldq, P, dS, B, Sq, Sk,
-                     heads, head_dim, dk, lddk, dv, lddv, drop);
+  hipLaunchKernelGGL(xattn_bwd_kv_kernel, dim3((unsigned)((rk + 3) / 4)), dim3(256), 0, st, dctx, ldc, q, ldq, Pv, dS, B, Sq, Sk,
+                     heads, head_dim, dk, lddk, dv, lddv);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
