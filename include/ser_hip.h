@@ -273,6 +273,11 @@ int ser_layernorm2_bwd(const float* du, const float* dres, const float* x, const
 int ser_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
 int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream);
 int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);
+/* activation followed by dropout in one pass, and its backward (see ser_dropout for the generator arguments) */
+int ser_act_drop_fwd(const float* x, int act, long long n, float* y, const void* drop_state, unsigned drop_site, float drop_p,
+                     void* stream);
+int ser_act_drop_bwd(const float* dy, const float* y, int act, long long n, float* dx, const void* drop_state,
+                     unsigned drop_site, float drop_p, void* stream);
 int ser_axpby(const float* x, float a, float b, long long n, float* y, void* stream); /* y = a x + b y */
 int ser_scale_dev(float* x, const float* s, long long n, void* stream);            /* x *= s[0], s on device */
 

@@ -191,6 +191,8 @@ _sig("ser_layernorm_bwd", i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32
 _sig("ser_colsum", i32, vp, i32, i32, i32, vp, i32, vp)
 _sig("ser_act_fwd", i32, vp, i32, i64, vp, vp)
 _sig("ser_act_bwd", i32, vp, vp, i32, i64, vp, vp)
+_sig("ser_act_drop_fwd", i32, vp, i32, i64, vp, vp, C.c_uint, f32, vp)
+_sig("ser_act_drop_bwd", i32, vp, vp, i32, i64, vp, vp, C.c_uint, f32, vp)
 _sig("ser_axpby", i32, vp, f32, f32, i64, vp, vp)
 _sig("ser_scale_dev", i32, vp, vp, i64, vp)
 _sig("ser_xattn_fwd", i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, C.c_uint, f32, vp, vp)

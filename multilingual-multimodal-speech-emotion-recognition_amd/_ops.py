@@ -249,15 +249,25 @@ def linear_wgrad(dy, x, dW, db=None, accumulate=False):
                                        nbytes, L.stream_ptr()), "ser_linear_wgrad")
 
 
-def act_fwd(x, act):
+def act_fwd(x, act, dctx=None, site=0):
+    """y = act(x), followed by dropout in the same pass when dctx is given."""
     y = torch.empty_like(x)
-    L.check(L.lib.ser_act_fwd(L.ptr(x), act, x.numel(), L.ptr(y), L.stream_ptr()), "ser_act_fwd")
+    if dctx is None:
+        L.check(L.lib.ser_act_fwd(L.ptr(x), act, x.numel(), L.ptr(y), L.stream_ptr()), "ser_act_fwd")
+    else:
+        L.check(L.lib.ser_act_drop_fwd(L.ptr(x), act, x.numel(), L.ptr(y), L.ptr(dctx[0]), int(site), dctx[1], L.stream_ptr()),
+                "ser_act_drop_fwd")
     return y
 
 
-def act_bwd(dy, y, act, inplace=True):
+def act_bwd(dy, y, act, inplace=True, dctx=None, site=0):
+    """dx = dy * act'(y); with dctx, y = dropout(act(x)) and the dropout mask is applied to dy in the same pass."""
     dx = dy if inplace else torch.empty_like(dy)
-    L.check(L.lib.ser_act_bwd(L.ptr(dy), L.ptr(y), act, dy.numel(), L.ptr(dx), L.stream_ptr()), "ser_act_bwd")
+    if dctx is None:
+        L.check(L.lib.ser_act_bwd(L.ptr(dy), L.ptr(y), act, dy.numel(), L.ptr(dx), L.stream_ptr()), "ser_act_bwd")
+    else:
+        L.check(L.lib.ser_act_drop_bwd(L.ptr(dy), L.ptr(y), act, dy.numel(), L.ptr(dx), L.ptr(dctx[0]), int(site), dctx[1],
+                                       L.stream_ptr()), "ser_act_drop_bwd")
     return dx
 
 

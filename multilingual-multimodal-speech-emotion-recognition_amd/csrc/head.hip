@@ -346,8 +346,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // dx = dy * act'(y) given the activation OUTPUT y
+// with `drop`: y was produced as dropout(act(x)); dx = dy * mask / (1 - p) * act'(y)  (for ReLU, y > 0 <=> active and kept)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, long long n,
-                               float* __restrict__ dx) {
+                               float* __restrict__ dx, SerDropout drop) {
+  const bool dropping = drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dst = dropping ? *drop.state : 0ull;
+  const unsigned dth = ser_drop_thresh(drop.p);
+  const float dsc = 1.0f / (1.0f - drop.p);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float yy = y[i];
     float d;
@@ -355,12 +360,17 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     else if (act == SER_ACT_TANH) d = 1.f - yy * yy;
     else if (act == SER_ACT_SIGMOID) d = yy * (1.f - yy);
     else d = 1.f;
+    if (dropping) d *= ser_drop_mult(dst, drop.site, (unsigned)i, dth, dsc);
     dx[i] = dy[i] * d;
   }
 }
 
-// y = act(x)
-__global__ void act_fwd_kernel(const float* __restrict__ x, int act, long long n, float* __restrict__ y) {
+// y = dropout(act(x))
+__global__ void act_fwd_kernel(const float* __restrict__ x, int act, long long n, float* __restrict__ y, SerDropout drop) {
+  const bool dropping = drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dst = dropping ? *drop.state : 0ull;
+  const unsigned dth = ser_drop_thresh(drop.p);
+  const float dsc = 1.0f / (1.0f - drop.p);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float v = x[i];
     float o;
@@ -369,6 +379,7 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, int act, long long n
     else if (act == SER_ACT_SIGMOID) o = 1.f / (1.f + expf(-v));
     else if (act == SER_ACT_GELU) o = gelu_erf(v);
     else o = v;
+    if (dropping) o *= ser_drop_mult(dst, drop.site, (unsigned)i, dth, dsc);
     y[i] = o;
   }
 }
@@ -1213,16 +1224,36 @@ extern "C" int ser_colsum(const float* x, int M, int N, int ld, float* out, int 
   return SER_OK;
 }
 
+extern "C" int ser_act_drop_bwd(const float* dy, const float* y, int act, long long n, float* dx, const void* drop_state,
+                                unsigned drop_site, float drop_p, void* stream) {
+  if (n <= 0) return SER_OK;
+  SER_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "act_drop_bwd: p=%f out of range", drop_p);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, act, n, dx,
+                     SerDropout{(const unsigned long long*)drop_state, drop_site, drop_p});
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_act_drop_fwd(const float* x, int act, long long n, float* y, const void* drop_state, unsigned drop_site,
+                                float drop_p, void* stream) {
+  if (n <= 0) return SER_OK;
+  SER_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "act_drop_fwd: p=%f out of range", drop_p);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, act, n, y,
+                     SerDropout{(const unsigned long long*)drop_state, drop_site, drop_p});
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 extern "C" int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream) {
   if (n <= 0) return SER_OK;
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, act, n, dx);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, dy, y, act, n, dx, SerDropout{nullptr, 0u, 0.f});
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
 
 extern "C" int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream) {
   if (n <= 0) return SER_OK;
-  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, act, n, y);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, act, n, y, SerDropout{nullptr, 0u, 0.f});
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

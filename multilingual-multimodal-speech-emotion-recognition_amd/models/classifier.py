@@ -71,10 +71,9 @@ class _ClassifierFn(torch.autograd.Function):
         ip, op = dc.input_projection, dc.output_projection
         t0 = O.linear_fwd(x, ip[0].weight, ip[0].bias)
         y0, ln0 = O.ln_fwd(t0, ip[1].weight, ip[1].bias)
-        h = O.act_fwd(y0, O.ACT_RELU)
         sites = m._drop_sites
         d_in, d_out, d_unc = O.dropout_ctx(ip[3].p), O.dropout_ctx(op[3].p), O.dropout_ctx(uh_[2].p)
-        O.dropout_(h, d_in, sites[0])                            # ref classifier.py:109
+        h = O.act_fwd(y0, O.ACT_RELU, d_in, sites[0])            # ReLU + Dropout (ref classifier.py:108-109)
         h0 = h
         blocks = []
         stack = None
@@ -116,8 +115,7 @@ class _ClassifierFn(torch.autograd.Function):
             blocks.append((lnA, lnB, u, a, hin, x1, stats, d_b))
         tf = O.linear_fwd(h, op[0].weight, op[0].bias)
         yf, lnF = O.ln_fwd(tf, op[1].weight, op[1].bias)
-        f = O.act_fwd(yf, O.ACT_RELU)
-        O.dropout_(f, d_out, sites[1])                           # ref classifier.py:127,218
+        f = O.act_fwd(yf, O.ACT_RELU, d_out, sites[1])           # ReLU + Dropout (ref classifier.py:126-127,218)
         logits = O.linear_fwd(f, op[4].weight, op[4].bias)
         uh = O.linear_fwd(f, uh_[0].weight, uh_[0].bias, O.ACT_RELU)
         O.dropout_(uh, d_unc, sites[2])                          # ref classifier.py:195
@@ -153,13 +151,11 @@ class _ClassifierFn(torch.autograd.Function):
         du2 = O.act_bwd(dunc, unc, O.ACT_SIGMOID, inplace=False)
         O.linear_wgrad(du2, uh, g(uh_[3].weight), g(uh_[3].bias), acc)
         duh = O.linear_dgrad(du2, uh_[3].weight)
-        O.dropout_(duh, d_unc, sites[2])
-        O.act_bwd(duh, uh, O.ACT_RELU)
+        O.act_bwd(duh, uh, O.ACT_RELU, dctx=d_unc, site=sites[2])
         O.linear_wgrad(duh, f, g(uh_[0].weight), g(uh_[0].bias), acc)
         O.linear_dgrad(duh, uh_[0].weight, out=df, accumulate=True)
         # output projection
-        O.dropout_(df, d_out, sites[1])
-        O.act_bwd(df, f, O.ACT_RELU)
+        O.act_bwd(df, f, O.ACT_RELU, dctx=d_out, site=sites[1])
         dtf = O.ln_bwd(df, lnF, op[1].weight, g(op[1].weight), g(op[1].bias), acc)
         O.linear_wgrad(dtf, h_last, g(op[0].weight), g(op[0].bias), acc)
         wg = []
@@ -201,8 +197,7 @@ class _ClassifierFn(torch.autograd.Function):
         if wg:
             O.linear_wgrad_batch(wg, acc)
         # input projection
-        O.dropout_(dh, d_in, sites[0])
-        O.act_bwd(dh, h0, O.ACT_RELU)
+        O.act_bwd(dh, h0, O.ACT_RELU, dctx=d_in, site=sites[0])
         dt0 = O.ln_bwd(dh, ln0, ip[1].weight, g(ip[1].weight), g(ip[1].bias), acc)
         O.linear_wgrad(dt0, x, g(ip[0].weight), g(ip[0].bias), acc)
         dx = O.linear_dgrad(dt0, ip[0].weight) if ctx.need_dx else None

@@ -25,8 +25,7 @@ def _branch_bwd(da, dgl, a, saved, proj, gate, g, acc, need_dx):
     O.linear_dgrad(dgh, gate[0].weight, out=da, accumulate=True)       # a feeds both the mix and its own gate
     O.linear_wgrad(da, h, g(proj[3].weight), g(proj[3].bias), acc)
     dh = O.linear_dgrad(da, proj[3].weight)
-    O.dropout_(dh, dctx, site)
-    O.act_bwd(dh, h, O.ACT_RELU)
+    O.act_bwd(dh, h, O.ACT_RELU, dctx=dctx, site=site)
     O.linear_wgrad(dh, x, g(proj[0].weight), g(proj[0].bias), acc)
     return O.linear_dgrad(dh, proj[0].weight) if need_dx else None
 
