@@ -45,11 +45,11 @@ def _dir_fwd(x_q, x_kv, kv_mask, B, Sq, Sk, Wq, bq, Wk, bk, Wv, bv, Wi, bi, Wo, 
 
 
 def _dir_bwd(dy, saved, x_q, x_kv, B, Sq, Sk, Wq, Wk, Wv, Wi, Wo, Wout, ng, g, acc, heads, dx_q, dx_kv):
-    """Accumulates input gradients into dx_q / dx_kv (already initialised) and writes parameter grads via g(param)."""
+    """Writes the input gradients into dx_q / dx_kv (uninitialised on entry) and the parameter grads via g(param)."""
     q1, k1, v1, Q, K, V, P, ctx, c2, ln, dout, site, dattn, site_attn = saved
     E = Wq["w"].shape[0]
     dz = O.ln_bwd(dy, ln, ng["w"], g(ng["w"]), g(ng["b"]), acc)
-    O.axpby(dz, dx_q, 1.0, 1.0)                                  # residual branch
+    O.axpby(dz, dx_q, 1.0, 0.0)                                  # residual branch: first write of dx_q (no zero fill needed)
     O.dropout_(dz, dout, site)                                   # from here on dz is the gradient at the dropped branch
     O.linear_wgrad(dz, c2, g(Wout["w"]), g(Wout["b"]), acc)
     dc2 = O.linear_dgrad(dz, Wout["w"])
@@ -67,7 +67,7 @@ def _dir_bwd(dy, saved, x_q, x_kv, B, Sq, Sk, Wq, Wk, Wv, Wi, Wo, Wout, ng, g, a
     O.linear_wgrad(dk1, x_kv, g(Wk["w"]), g(Wk["b"]), acc)
     O.linear_wgrad(dv1, x_kv, g(Wv["w"]), g(Wv["b"]), acc)
     O.linear_dgrad(dq1, Wq["w"], out=dx_q, accumulate=True)
-    O.linear_dgrad(dk1, Wk["w"], out=dx_kv, accumulate=True)
+    O.linear_dgrad(dk1, Wk["w"], out=dx_kv, accumulate=False)          # first write of dx_kv
     O.linear_dgrad(dv1, Wv["w"], out=dx_kv, accumulate=True)
 
 
@@ -109,10 +109,10 @@ class _CrossFn(torch.autograd.Function):
         P = lambda mod: {"w": mod.weight, "b": mod.bias}
         PI = lambda mha: {"w": mha.in_proj_weight, "b": mha.in_proj_bias}
         dev = dya.device
-        da = torch.zeros(B * Sa, Da, dtype=torch.float32, device=dev)
-        dt = torch.zeros(B * St, Dt, dtype=torch.float32, device=dev)
-        da2 = torch.zeros(B * Sa, Da, dtype=torch.float32, device=dev)      # contributions of the other direction
-        dt2 = torch.zeros(B * St, Dt, dtype=torch.float32, device=dev)
+        da = torch.empty(B * Sa, Da, dtype=torch.float32, device=dev)       # every buffer is fully written by its first use
+        dt = torch.empty(B * St, Dt, dtype=torch.float32, device=dev)
+        da2 = torch.empty(B * Sa, Da, dtype=torch.float32, device=dev)      # contributions of the other direction
+        dt2 = torch.empty(B * St, Dt, dtype=torch.float32, device=dev)
         dya2, dyt2 = dya.reshape(B * Sa, Da).contiguous(), dyt.reshape(B * St, Dt).contiguous()
         cur = torch.cuda.current_stream()
         side = _side_stream()
