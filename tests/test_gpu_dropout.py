@@ -163,6 +163,123 @@ def test_classifier_gradients_consistent_under_dropout_on_both_paths(OP):
         _directional_check(f, [x] + [p for p in m.deep_classifier.parameters()][:6], rel=5e-2)
 
 
+@pytest.mark.parametrize("rows", [8, 16, 24])
+def test_classifier_dropout_against_torch_autograd_with_the_same_masks(OP, rows):
+    """The multipliers of a site are observable (dropout of a ones tensor), so the whole classifier under dropout can be
+    restated with torch ops in float64 and differentiated by autograd: outputs and every gradient must match the HIP
+    path (persistent stack for rows <= 16, launch-per-Linear beyond) to fp32 accuracy."""
+    import torch.nn.functional as F
+    from ser_amd.models.classifier import AdvancedOpenMaxClassifier
+    torch.manual_seed(11 + rows)
+    D, depth, p = 128, 3, 0.25
+    m = AdvancedOpenMaxClassifier(input_dim=D, num_labels=4, num_layers=depth, base_dim=D, dropout=p).cuda().train()
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.add_(0.05 * torch.randn_like(prm))
+    st = _state(1234)
+    x = torch.randn(rows, D, device="cuda", requires_grad=True)
+    gl, gu = torch.randn(rows, 4, device="cuda"), torch.randn(rows, 1, device="cuda")
+    with OP.dropout_scope(st):
+        logits, unc, _ = m(x, use_openmax=False, return_uncertainty=True)
+    torch.autograd.backward([logits, unc], [gl, gu])
+    torch.cuda.synchronize()
+    got = {k: prm.grad.double().clone() for k, prm in m.named_parameters() if prm.grad is not None}
+    gx = x.grad.double().clone()
+
+    def mult(site, shape):
+        return OP.dropout_(torch.ones(shape, device="cuda"), (st, p), site).double()
+
+    sites = m._drop_sites
+    P = {k: v.detach().double().requires_grad_() for k, v in m.named_parameters()}
+    xd = x.detach().double().requires_grad_()
+    dc = "deep_classifier."
+    ln = lambda t_, pre: F.layer_norm(t_, (t_.shape[1],), P[pre + ".weight"], P[pre + ".bias"], 1e-5)
+    lin = lambda t_, pre: t_ @ P[pre + ".weight"].t() + P[pre + ".bias"]
+    h = F.relu(ln(lin(xd, dc + "input_projection.0"), dc + "input_projection.1")) * mult(sites[0], (rows, D))
+    for i in range(depth):
+        x1 = ln(h, dc + f"layer_norms.{i}")
+        u = ln(x1, dc + f"residual_layers.{i}.block.0")
+        a = F.relu(lin(u, dc + f"residual_layers.{i}.block.1")) * mult(sites[3] + 2 * i, (rows, D))
+        h = x1 + lin(a, dc + f"residual_layers.{i}.block.4") * mult(sites[3] + 2 * i + 1, (rows, D))
+    f = F.relu(ln(lin(h, dc + "output_projection.0"), dc + "output_projection.1")) * mult(sites[1], (rows, D // 2))
+    ref_logits = lin(f, dc + "output_projection.4")
+    uh = F.relu(lin(f, "uncertainty_head.0")) * mult(sites[2], (rows, 64))
+    ref_unc = torch.sigmoid(lin(uh, "uncertainty_head.3"))
+    torch.autograd.backward([ref_logits, ref_unc], [gl.double(), gu.double()])
+
+    def close(a, b, what):
+        a, b = a.detach(), b.detach()
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * (float(b.abs().max()) + 1e-12), err_msg=what)
+
+    close(logits.double(), ref_logits.detach(), "logits")
+    close(unc.double(), ref_unc.detach(), "uncertainty")
+    close(gx, xd.grad, "input gradient")
+    for k, g_ in got.items():
+        if P[k].grad is not None:
+            close(g_, P[k].grad, k)
+
+
+@pytest.mark.parametrize("Sa,St,heads,E", [(40, 9, 2, 64), (300, 20, 2, 64)])
+def test_cross_attention_dropout_against_torch_autograd_with_the_same_masks(OP, Sa, St, heads, E):
+    """Attention-probability dropout (inside the xattn kernels: LDS-staged path for S <= 256, generic beyond) and the
+    block-output dropout, restated with torch ops in float64 using the observed multipliers of each site."""
+    import torch.nn.functional as F
+    from ser_amd.models.cross_attention import CrossModalAttention
+    torch.manual_seed(Sa + St)
+    B, D, p = 2, 64, 0.2
+    m = CrossModalAttention(D, D, shared_dim=E, num_heads=heads, dropout=p).cuda().train()
+    st = _state(77)
+    a = torch.randn(B, Sa, D, device="cuda", requires_grad=True)
+    t_ = torch.randn(B, St, D, device="cuda", requires_grad=True)
+    am, tm = torch.ones(B, Sa, device="cuda"), torch.ones(B, St, device="cuda")
+    tm[0, -2:] = 0
+    ga, gt = torch.randn(B, Sa, D, device="cuda"), torch.randn(B, St, D, device="cuda")
+    with OP.dropout_scope(st):
+        ya, yt = m(a, t_, am, tm)
+    torch.autograd.backward([ya, yt], [ga, gt])
+    torch.cuda.synchronize()
+    got = {k: prm.grad.double().clone() for k, prm in m.named_parameters() if prm.grad is not None}
+    g_a, g_t = a.grad.double().clone(), t_.grad.double().clone()
+
+    def mult(site, shape):
+        return OP.dropout_(torch.ones(shape, device="cuda"), (st, p), site).double()
+
+    P = {k: v.detach().double().requires_grad_() for k, v in m.named_parameters()}
+    ad, td = a.detach().double().requires_grad_(), t_.detach().double().requires_grad_()
+    lin = lambda x_, pre: x_ @ P[pre + ".weight"].t() + P[pre + ".bias"]
+    hd = E // heads
+
+    def direction(xq, xkv, kmask, q, k, v, attn, out, norm, site_out, site_attn):
+        Sq, Sk = xq.shape[1], xkv.shape[1]
+        Wi, bi = P[attn + ".in_proj_weight"], P[attn + ".in_proj_bias"]
+        Q = lin(xq, q) @ Wi[:E].t() + bi[:E]
+        K = lin(xkv, k) @ Wi[E:2 * E].t() + bi[E:2 * E]
+        V = lin(xkv, v) @ Wi[2 * E:].t() + bi[2 * E:]
+        split = lambda z, S: z.view(B, S, heads, hd).transpose(1, 2)
+        sc = split(Q, Sq) @ split(K, Sk).transpose(-1, -2) / hd ** 0.5
+        sc = sc.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+        Pm = torch.softmax(sc, -1) * mult(site_attn, (B, heads, Sq, Sk))
+        ctx = (Pm @ split(V, Sk)).transpose(1, 2).reshape(B, Sq, E)
+        o = lin(lin(ctx, attn + ".out_proj"), out) * mult(site_out, (B * Sq, D)).view(B, Sq, D)
+        return F.layer_norm(xq + o, (D,), P[norm + ".weight"], P[norm + ".bias"], 1e-5)
+
+    s_ = m._drop_sites
+    ra = direction(ad, td, tm.double(), "q_a", "k_t", "v_t", "attn_a", "out_a", "norm_a", s_[0], s_[2])
+    rt = direction(td, ad, am.double(), "q_t", "k_a", "v_a", "attn_t", "out_t", "norm_t", s_[1], s_[3])
+    torch.autograd.backward([ra, rt], [ga.double(), gt.double()])
+
+    def close(u, v, what):
+        u, v = u.detach(), v.detach()
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-4, atol=3e-5 * (float(v.abs().max()) + 1e-12), err_msg=what)
+
+    close(ya.double(), ra, "audio output")
+    close(yt.double(), rt, "text output")
+    close(g_a, ad.grad, "audio input gradient")
+    close(g_t, td.grad, "text input gradient")
+    for k, g_ in got.items():
+        close(g_, P[k].grad, k)
+
+
 def test_system_dropout_is_deterministic_and_replays_draw_new_masks():
     import __graft_entry__ as ge
     from ser_amd.system import TrainStepper
