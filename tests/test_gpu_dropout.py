@@ -269,8 +269,9 @@ def test_cross_attention_dropout_against_torch_autograd_with_the_same_masks(OP, 
     torch.autograd.backward([ra, rt], [ga.double(), gt.double()])
 
     def close(u, v, what):
+        # the key biases have an exactly-zero gradient (softmax is shift invariant): absolute floor at fp32 round-off
         u, v = u.detach(), v.detach()
-        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-4, atol=3e-5 * (float(v.abs().max()) + 1e-12), err_msg=what)
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=3e-4, atol=3e-5 * float(v.abs().max()) + 5e-6, err_msg=what)
 
     close(ya.double(), ra, "audio output")
     close(yt.double(), rt, "text output")
