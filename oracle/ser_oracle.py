@@ -77,8 +77,49 @@ def sub(sd: SD, prefix: str) -> SD:
     return {k[n:]: v for k, v in sd.items() if k.startswith(prefix)}
 
 
+# ----------------------------------------------------------------------------
+# A0  Training-mode dropout: y = x * m / (1 - p).  No RNG stream can match torch's, so the build defines its own
+# counter-based mask generator (csrc/ser_common.h: ser_drop_mult, keyed by a 64-bit state, a layer id and the flat
+# element index); this is its restatement, so that the oracle can run a training step with the SAME masks.
+# Layer ids are those SERSystem assigns (system.py): cross 1-4 (output a, output t, attention a, attention t),
+# fusion 5-6, classifier 7 (input projection), 8 (output projection), 9 (uncertainty head), 16 + 2 i (+1) block i.
+# ----------------------------------------------------------------------------
+
+def _mix32(h):
+    import numpy as np
+    h = h.astype(np.uint32)
+    h ^= h >> np.uint32(16); h = (h * np.uint32(0x85EBCA6B)).astype(np.uint32)
+    h ^= h >> np.uint32(13); h = (h * np.uint32(0xC2B2AE35)).astype(np.uint32)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def dropout_mult(state: int, site: int, shape, p: float) -> Tensor:
+    """Multipliers (0 or 1 / (1 - p)) of one dropout layer for a tensor of `shape` (flat element index = C order)."""
+    import numpy as np
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint32)
+        lo, hi = np.uint32(state & 0xFFFFFFFF), np.uint32((state >> 32) & 0xFFFFFFFF)
+        h = _mix32((idx * np.uint32(0x9E3779B1)).astype(np.uint32) ^ lo)
+        h = _mix32((h + np.uint32(site) * np.uint32(0x85EBCA77) + hi).astype(np.uint32))
+    thresh = np.uint32(min(np.float32(p) * np.float32(4294967296.0), np.float32(4294967040.0)))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return torch.from_numpy(np.where(h >= thresh, scale, np.float32(0.0)).astype(np.float32).reshape(shape))
+
+
+class DropoutPlan:
+    """The masks of one training step: `state` = the generator state of that step, p per module as constructed."""
+
+    def __init__(self, state: int, p_cross: float = 0.1, p_fusion: float = 0.1, p_classifier: float = 0.15):
+        self.state, self.p_cross, self.p_fusion, self.p_classifier = int(state), p_cross, p_fusion, p_classifier
+
+    def mult(self, site: int, shape, p: float) -> Tensor:
+        return dropout_mult(self.state, site, tuple(shape), p)
+
+
 def mha_core(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float,
-             key_bias: Optional[Tensor]) -> Tensor:
+             key_bias: Optional[Tensor], p_mult: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T * scale + key_bias) v per head.  q [B,Sq,D] k,v [B,Sk,D];
     key_bias [B,Sk] additive (0 / -inf) or None."""
     B, Sq, D = q.shape
@@ -91,6 +132,8 @@ def mha_core(q: Tensor, k: Tensor, v: Tensor, heads: int, scale: float,
     if key_bias is not None:
         s = s + key_bias[:, None, None, :]
     p = torch.softmax(s, dim=-1)
+    if p_mult is not None:                       # attention-probability dropout, [B, heads, Sq, Sk]
+        p = p * p_mult
     o = p @ vh
     return o.transpose(1, 2).reshape(B, Sq, D)
 
@@ -261,7 +304,8 @@ def text_encoder_forward(sd: SD, ids: Tensor, attn_mask: Tensor, cfg) -> Tuple[T
 # ----------------------------------------------------------------------------
 
 def _cross_dir(x_q: Tensor, x_kv: Tensor, kv_mask: Optional[Tensor], sd: SD,
-               q: str, k: str, v: str, attn: str, out: str, norm: str, heads: int) -> Tensor:
+               q: str, k: str, v: str, attn: str, out: str, norm: str, heads: int,
+               drop: Optional["DropoutPlan"] = None, site_out: int = 0, site_attn: int = 0) -> Tensor:
     E = sd[f"{q}.weight"].shape[0]
     qq = linear(x_q, sd[f"{q}.weight"], sd[f"{q}.bias"])
     kk = linear(x_kv, sd[f"{k}.weight"], sd[f"{k}.bias"])
@@ -273,16 +317,22 @@ def _cross_dir(x_q: Tensor, x_kv: Tensor, kv_mask: Optional[Tensor], sd: SD,
     key_bias = None
     if kv_mask is not None:
         key_bias = torch.zeros(kv_mask.shape, dtype=torch.float32).masked_fill(kv_mask == 0, float("-inf"))
-    ctx = mha_core(qq, kk, vv, heads, (E // heads) ** -0.5, key_bias)
+    pm = None
+    if drop is not None:
+        pm = drop.mult(site_attn, (x_q.shape[0], heads, x_q.shape[1], x_kv.shape[1]), drop.p_cross)
+    ctx = mha_core(qq, kk, vv, heads, (E // heads) ** -0.5, key_bias, pm)
     ctx = linear(ctx, sd[f"{attn}.out_proj.weight"], sd[f"{attn}.out_proj.bias"])
     o = linear(ctx, sd[f"{out}.weight"], sd[f"{out}.bias"])
+    if drop is not None:
+        o = o * drop.mult(site_out, o.shape, drop.p_cross)
     return layer_norm(x_q + o, sd[f"{norm}.weight"], sd[f"{norm}.bias"], 1e-5)
 
 
 def cross_attention_forward(sd: SD, a: Tensor, t: Tensor, a_mask: Optional[Tensor],
-                            t_mask: Optional[Tensor], heads: int = 8) -> Tuple[Tensor, Tensor]:
-    a_enh = _cross_dir(a, t, t_mask, sd, "q_a", "k_t", "v_t", "attn_a", "out_a", "norm_a", heads)
-    t_enh = _cross_dir(t, a, a_mask, sd, "q_t", "k_a", "v_a", "attn_t", "out_t", "norm_t", heads)
+                            t_mask: Optional[Tensor], heads: int = 8,
+                            drop: Optional["DropoutPlan"] = None) -> Tuple[Tensor, Tensor]:
+    a_enh = _cross_dir(a, t, t_mask, sd, "q_a", "k_t", "v_t", "attn_a", "out_a", "norm_a", heads, drop, 1, 3)
+    t_enh = _cross_dir(t, a, a_mask, sd, "q_t", "k_a", "v_a", "attn_t", "out_t", "norm_t", heads, drop, 2, 4)
     return a_enh, t_enh
 
 
@@ -305,12 +355,14 @@ def pooling_forward(sd: SD, x: Tensor, mask: Optional[Tensor]) -> Tensor:
 # A5  FusionLayer (ref: models/fusion.py:18-25)
 # ----------------------------------------------------------------------------
 
-def fusion_forward(sd: SD, a_vec: Tensor, t_vec: Tensor) -> Tensor:
-    def mlp(x, p0, p1):
-        return linear(torch.relu(linear(x, sd[p0 + ".weight"], sd[p0 + ".bias"])),
-                      sd[p1 + ".weight"], sd[p1 + ".bias"])
-    a = mlp(a_vec, "proj_a.0", "proj_a.3")
-    t = mlp(t_vec, "proj_t.0", "proj_t.3")
+def fusion_forward(sd: SD, a_vec: Tensor, t_vec: Tensor, drop: Optional["DropoutPlan"] = None) -> Tensor:
+    def mlp(x, p0, p1, site=0):
+        h = torch.relu(linear(x, sd[p0 + ".weight"], sd[p0 + ".bias"]))
+        if drop is not None and site:
+            h = h * drop.mult(site, h.shape, drop.p_fusion)
+        return linear(h, sd[p1 + ".weight"], sd[p1 + ".bias"])
+    a = mlp(a_vec, "proj_a.0", "proj_a.3", 5)
+    t = mlp(t_vec, "proj_t.0", "proj_t.3", 6)
     wa = torch.sigmoid(mlp(a, "gate_a.0", "gate_a.2"))
     wt = torch.sigmoid(mlp(t, "gate_t.0", "gate_t.2"))
     ws = wa + wt + 1e-8
@@ -321,19 +373,21 @@ def fusion_forward(sd: SD, a_vec: Tensor, t_vec: Tensor) -> Tensor:
 # A6  AdvancedOpenMaxClassifier (ref: models/classifier.py:200-305)
 # ----------------------------------------------------------------------------
 
-def classifier_features(sd: SD, x: Tensor, num_layers: int) -> Tensor:
+def classifier_features(sd: SD, x: Tensor, num_layers: int, drop: Optional["DropoutPlan"] = None) -> Tensor:
     """Penultimate 256-d features (ref :203-218; same loop as train.py:222-236)."""
     d = "deep_classifier."
+    dm = (lambda site, t_: t_ * drop.mult(site, t_.shape, drop.p_classifier)) if drop is not None else (lambda site, t_: t_)
     h = torch.relu(layer_norm(linear(x, sd[d + "input_projection.0.weight"], sd[d + "input_projection.0.bias"]),
                               sd[d + "input_projection.1.weight"], sd[d + "input_projection.1.bias"], 1e-5))
+    h = dm(7, h)
     for i in range(num_layers):
         h = layer_norm(h, sd[d + f"layer_norms.{i}.weight"], sd[d + f"layer_norms.{i}.bias"], 1e-5)
         r = d + f"residual_layers.{i}.block."
         u = layer_norm(h, sd[r + "0.weight"], sd[r + "0.bias"], 1e-5)
-        u = torch.relu(linear(u, sd[r + "1.weight"], sd[r + "1.bias"]))
-        h = h + linear(u, sd[r + "4.weight"], sd[r + "4.bias"])
+        u = dm(16 + 2 * i, torch.relu(linear(u, sd[r + "1.weight"], sd[r + "1.bias"])))
+        h = h + dm(16 + 2 * i + 1, linear(u, sd[r + "4.weight"], sd[r + "4.bias"]))
     f = linear(h, sd[d + "output_projection.0.weight"], sd[d + "output_projection.0.bias"])
-    return torch.relu(layer_norm(f, sd[d + "output_projection.1.weight"], sd[d + "output_projection.1.bias"], 1e-5))
+    return dm(8, torch.relu(layer_norm(f, sd[d + "output_projection.1.weight"], sd[d + "output_projection.1.bias"], 1e-5)))
 
 
 def openmax_adjust(sd: SD, feats: Tensor, logits: Tensor) -> Tensor:
@@ -349,11 +403,13 @@ def openmax_adjust(sd: SD, feats: Tensor, logits: Tensor) -> Tensor:
 
 
 def classifier_forward(sd: SD, x: Tensor, num_layers: int = 35, use_openmax: bool = True,
-                       training: bool = False):
+                       training: bool = False, drop: Optional["DropoutPlan"] = None):
     """-> (logits, uncertainty [B,1], anchor_loss (exactly 0.), features)."""
-    f = classifier_features(sd, x, num_layers)
+    f = classifier_features(sd, x, num_layers, drop)
     logits = linear(f, sd["deep_classifier.output_projection.4.weight"], sd["deep_classifier.output_projection.4.bias"])
     u = torch.relu(linear(f, sd["uncertainty_head.0.weight"], sd["uncertainty_head.0.bias"]))
+    if drop is not None:
+        u = u * drop.mult(9, u.shape, drop.p_classifier)
     unc = torch.sigmoid(linear(u, sd["uncertainty_head.3.weight"], sd["uncertainty_head.3.bias"]))
     if use_openmax and not training:
         logits = openmax_adjust(sd, f, logits)
@@ -459,13 +515,13 @@ def lr_lambda(step: int, total_steps: int, warmup_ratio: float) -> float:
 
 def full_forward(sds: Dict[str, SD], waves: Sequence[Tensor], ids: Tensor, attn_mask: Tensor,
                  a_cfg, t_cfg, num_layers: int = 35, heads: int = 8, use_openmax: bool = False,
-                 training: bool = True):
+                 training: bool = True, drop: Optional["DropoutPlan"] = None):
     a_seq, a_mask = audio_encoder_forward(sds["audio_encoder"], waves, a_cfg)
     t_seq, t_mask = text_encoder_forward(sds["text_encoder"], ids, attn_mask, t_cfg)
-    a_enh, t_enh = cross_attention_forward(sds["cross"], a_seq, t_seq, a_mask, t_mask, heads)
+    a_enh, t_enh = cross_attention_forward(sds["cross"], a_seq, t_seq, a_mask, t_mask, heads, drop)
     a_vec = pooling_forward(sds["pool_a"], a_enh, a_mask)
     t_vec = pooling_forward(sds["pool_t"], t_enh, t_mask)
-    fused = fusion_forward(sds["fusion"], a_vec, t_vec)
-    logits, unc, anchor, feats = classifier_forward(sds["classifier"], fused, num_layers, use_openmax, training)
+    fused = fusion_forward(sds["fusion"], a_vec, t_vec, drop)
+    logits, unc, anchor, feats = classifier_forward(sds["classifier"], fused, num_layers, use_openmax, training, drop)
     return dict(a_seq=a_seq, t_seq=t_seq, a_enh=a_enh, t_enh=t_enh, a_vec=a_vec, t_vec=t_vec,
                 fused=fused, logits=logits, unc=unc, feats=feats)

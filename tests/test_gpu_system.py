@@ -152,3 +152,49 @@ def test_variable_length_clips_pad_like_reference():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_train_step_with_dropout_matches_oracle_with_the_same_masks():
+    """Training-mode parity INCLUDING dropout: the oracle restates the mask generator (O.dropout_mult) and applies the
+    masks of the same step at the same 13 + 2 x depth sites; logits, loss and every gradient must then agree with the
+    HIP path (fused masks inside the persistent classifier and attention kernels) as tightly as without dropout."""
+    import __graft_entry__ as ge
+    from ser_amd import _ops as OP
+    dev = torch.device("cuda:0")
+    sysm, wc, xc = ge._small_system(dev, train_dropout=True)
+    sysm.train()
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    wave, ids, mask, labels = _batch(11)
+    sds = {k: {n: v.detach().cpu().clone() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
+
+    loss, logits = sysm.loss(wave.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    state = int(sysm._drop_state.item())
+    assert state == sysm.dropout_seed + 1
+    # the generator itself: device multipliers == the oracle's restatement, bit for bit
+    for site, shape, p in ((7, (4, 64), 0.15), (3, (4, 2, 12, 9), 0.1), (21, (16, 512), 0.15)):
+        dev_m = OP.dropout_(torch.ones(shape, device=dev), (sysm._drop_state, p), site).cpu()
+        assert torch.equal(dev_m, O.dropout_mult(state, site, shape, p)), (site, shape)
+
+    plan = O.DropoutPlan(state, p_cross=sysm.cross.dropout.p, p_fusion=0.1, p_classifier=0.15)
+    leaf = {k: {n: v.clone().requires_grad_(v.dtype.is_floating_point and not n.startswith("encoder."))
+                for n, v in sd.items()} for k, sd in sds.items()}
+    out = O.full_forward(leaf, list(wave), ids, mask, a_cfg, t_cfg, num_layers=3, heads=2, use_openmax=False, training=True,
+                         drop=plan)
+    ref_loss = O.train_loss(out["logits"], out["unc"], out["fused"], leaf["prototypes"]["prototypes"], labels, 4)
+    ref_loss.backward()
+    nodrop = O.full_forward(sds, list(wave), ids, mask, a_cfg, t_cfg, num_layers=3, heads=2, use_openmax=False, training=True)
+    assert (out["logits"] - nodrop["logits"]).abs().max().item() > 1e-2, "the plan must actually drop something"
+
+    assert (logits.cpu() - out["logits"]).abs().max().item() < 1e-3
+    assert torch.equal(logits.argmax(1).cpu(), out["logits"].argmax(1))
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    for key in sysm.CKPT_KEYS:
+        named = dict(getattr(sysm, key).named_parameters())
+        for n, v in leaf[key].items():
+            if v.grad is None or n not in named or named[n].grad is None:
+                continue
+            denom = max(v.grad.abs().max().item(), 1e-3)
+            rel = (named[n].grad.cpu() - v.grad).abs().max().item() / denom
+            assert rel < 2e-2, f"{key}.{n}: gradient differs from the oracle under dropout (rel {rel:.3e})"

@@ -138,3 +138,18 @@ def test_adamw_and_lr_schedule():
             assert abs(lr - r["lrs"][s, col]) < 1e-12
             p, m, v = O.adamw_step(p, t(r[f"g{name[1]}_{s}"]), m, v, s + 1, lr, wd)
             np.testing.assert_allclose(p.numpy(), r[f"{name}_{s + 1}"], atol=1e-6, rtol=1e-5)
+
+
+def test_dropout_mask_generator_restatement_properties():
+    """O.dropout_mult restates the device mask generator (csrc/ser_common.h: ser_drop_mult); the bit-for-bit check
+    against the device is in tests/test_gpu_system.py.  Here: keep rate, scaling, determinism, independence."""
+    import numpy as np
+    a = O.dropout_mult(0x5EEE, 7, (256, 512), 0.15)
+    assert abs(float((a != 0).float().mean()) - 0.85) < 3e-3
+    np.testing.assert_allclose(a[a != 0].numpy(), 1 / 0.85, rtol=1e-6)
+    assert torch.equal(a, O.dropout_mult(0x5EEE, 7, (256, 512), 0.15))
+    for st, site in ((0x5EEF, 7), (0x5EEE, 8), (0x5EEE + (1 << 32), 7)):
+        b = O.dropout_mult(st, site, (256, 512), 0.15)
+        agree = float(((a != 0) == (b != 0)).float().mean())
+        assert abs(agree - (0.85 ** 2 + 0.15 ** 2)) < 5e-3
+    assert float(O.dropout_mult(1, 1, (1000,), 0.0).min()) == 1.0
