@@ -74,7 +74,8 @@ def cpu_baseline_and_parity(sysm, wc, xc, args, dev):
     wave, ids, mask, labels = synth_batch(Bc, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels, 4321)
     sds = {k: {n: v.detach().cpu() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
     a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
-    tr = OracleTrainer(sds, a_cfg, t_cfg, num_layers=35, heads=8, num_labels=sysm.num_labels)
+    tr = OracleTrainer(sds, a_cfg, t_cfg, num_layers=35, heads=8, num_labels=sysm.num_labels,
+                       dropout_seed=sysm.dropout_seed if sysm.train_dropout else None)      # same train-mode step as the HIP path
     ref = tr.forward(list(wave), ids, mask, use_openmax=False, training=True)
     sysm.train()
     with torch.no_grad():
@@ -84,7 +85,7 @@ def cpu_baseline_and_parity(sysm, wc, xc, args, dev):
     sec = time_steps(tr, list(wave), ids, mask, labels, warmup=1, steps=args.cpu_steps)
     ncores = torch.get_num_threads()
     base = dict(value=round(Bc / sec, 4), unit="utt/s", cores=ncores, kind="port",
-                sample=f"{args.cpu_steps} timed train steps (fwd+loss+bwd+AdamW) of oracle/cpu_step.py at batch {Bc}, "
+                sample=f"{args.cpu_steps} timed train steps (fwd+loss+bwd+AdamW, head dropout on) of oracle/cpu_step.py at batch {Bc}, "
                        f"{args.seconds:g} s audio + {args.tokens} tokens, PyTorch-CPU fp32, {ncores} threads")
     return base, err, same
 

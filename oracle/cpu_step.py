@@ -25,8 +25,12 @@ def _classifier_group(name):
 
 
 class OracleTrainer:
-    def __init__(self, sds, a_cfg, t_cfg, num_layers=35, heads=8, num_labels=4, lr=1e-4):
+    def __init__(self, sds, a_cfg, t_cfg, num_layers=35, heads=8, num_labels=4, lr=1e-4, dropout_seed=None,
+                 p_cross=0.1, p_fusion=0.1, p_classifier=0.15):
+        """dropout_seed: when given, every step applies the head's training-mode dropout with the masks of the build's
+        generator (state = seed + step), i.e. the CPU baseline times the same train-mode step the HIP path runs."""
         self.a_cfg, self.t_cfg, self.L, self.heads, self.C, self.lr = a_cfg, t_cfg, num_layers, heads, num_labels, lr
+        self.dropout_seed, self.p = dropout_seed, (p_cross, p_fusion, p_classifier)
         self.sds = {k: {n: v.detach().clone().float() if v.dtype.is_floating_point else v.clone() for n, v in sd.items()}
                     for k, sd in sds.items()}
         self.state = {}
@@ -53,10 +57,13 @@ class OracleTrainer:
         a_seq = O.adapter(enc_a, O.sub(self.sds["audio_encoder"], "adapter."))
         t_seq = O.adapter(enc_t, O.sub(self.sds["text_encoder"], "adapter."))
         a_mask, t_mask = torch.ones(a_seq.shape[:2]), mask.float()
-        a_enh, t_enh = O.cross_attention_forward(self.sds["cross"], a_seq, t_seq, a_mask, t_mask, self.heads)
+        drop = None
+        if self.dropout_seed is not None:
+            drop = O.DropoutPlan(self.dropout_seed + self.t + 1, *self.p)
+        a_enh, t_enh = O.cross_attention_forward(self.sds["cross"], a_seq, t_seq, a_mask, t_mask, self.heads, drop)
         fused = O.fusion_forward(self.sds["fusion"], O.pooling_forward(self.sds["pool_a"], a_enh, a_mask),
-                                 O.pooling_forward(self.sds["pool_t"], t_enh, t_mask))
-        logits, unc, _, _ = O.classifier_forward(self.sds["classifier"], fused, self.L, False, True)
+                                 O.pooling_forward(self.sds["pool_t"], t_enh, t_mask), drop)
+        logits, unc, _, _ = O.classifier_forward(self.sds["classifier"], fused, self.L, False, True, drop)
         loss = O.train_loss(logits, unc, fused, self.sds["prototypes"]["prototypes"], labels, self.C)
         loss.backward()
         self.t += 1

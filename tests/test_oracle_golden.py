@@ -153,3 +153,24 @@ def test_dropout_mask_generator_restatement_properties():
         agree = float(((a != 0) == (b != 0)).float().mean())
         assert abs(agree - (0.85 ** 2 + 0.15 ** 2)) < 5e-3
     assert float(O.dropout_mult(1, 1, (1000,), 0.0).min()) == 1.0
+
+
+def test_cpu_train_step_applies_the_dropout_plan_deterministically():
+    """oracle/cpu_step.py (bench.py's cpu_baseline leg): with a dropout seed the step draws the head's masks from the
+    build's generator (state = seed + step) — same seed same losses, other seed / no dropout other losses."""
+    import __graft_entry__ as ge
+    from oracle.cpu_step import OracleTrainer
+    sysm, wc, xc = ge._small_system("cpu")
+    sds = {k: {n: v.detach() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    g = torch.Generator().manual_seed(1)
+    wave, ids = 0.1 * torch.randn(2, 4000, generator=g), torch.randint(4, 1000, (2, 8), generator=g)
+    mask, labels = torch.ones(2, 8), torch.tensor([1, 2])
+
+    def losses(seed):
+        tr = OracleTrainer(sds, a_cfg, t_cfg, num_layers=3, heads=2, num_labels=4, dropout_seed=seed)
+        return [tr.step(list(wave), ids, mask, labels)[0] for _ in range(2)]
+
+    off, a, b, c = losses(None), losses(7), losses(7), losses(8)
+    assert a == b and a != c and a != off
+    assert all(np.isfinite(x) for x in off + a + c)
