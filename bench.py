@@ -129,7 +129,10 @@ def main():
     from ser_amd.system import GradReducer, TrainStepper
     from ser_amd import _lib as L
     if os.environ.get("SER_GEMM_STAGES"):
-        L.lib.ser_debug_set_gemm_stages(*[int(v) for v in os.environ["SER_GEMM_STAGES"].split(",")])
+        st = [int(v) for v in os.environ["SER_GEMM_STAGES"].split(",")]
+        L.lib.ser_debug_set_gemm_stages(*st[:4])
+        if len(st) == 7:                                   # ... ,96x128,160x128,192x128
+            L.lib.ser_debug_set_gemm_stages_tall(*st[4:])
     if os.environ.get("SER_GEMM_LDS_PAD"):
         L.lib.ser_debug_set_gemm_lds_pad(int(os.environ["SER_GEMM_LDS_PAD"]))
     if os.environ.get("SER_GEMM_PERSIST"):

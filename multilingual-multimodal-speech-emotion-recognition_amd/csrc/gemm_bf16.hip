@@ -18,6 +18,14 @@
 
 namespace {
 
+// Phase probe (scripts/gemm_phase_probe.py builds side libraries with -DSER_GEMM_DIAG=n; the product build has 0):
+// bit 0 drops the epilogue, bit 1 the fragment reads + MFMAs, bit 2 the global->LDS staging, bit 3 the epilogue's
+// global stores (its LDS pass and arithmetic stay).  Timing only — the
+// results of a probe build are meaningless.
+#ifndef SER_GEMM_DIAG
+#define SER_GEMM_DIAG 0
+#endif
+
 constexpr int BK = 64;           // bf16 elements per k-tile = 128 B per row
 constexpr int ROW_BYTES = 128;
 
@@ -133,6 +141,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
   stage_offsets<BM>(offa, g.lda, m0, g.M - 1, wave, lane);
   stage_offsets<BN>(offw, g.ldw, n0, g.N - 1, wave, lane);
   auto stage = [&](int kt, int buf) {
+    if (SER_GEMM_DIAG & 4) return;
     char* s = lds + buf * STAGE;
     stage_tile<BM>(a_hi + kt * BK, offa, s, wave);
     stage_tile<BN>(w_hi + kt * BK, offw, s + A_TILE * NPL, wave);
@@ -155,35 +164,56 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     if (NS >= 4 && ahead >= 2) wait_dma_barrier<(NS >= 4 ? 2 : 0) * GLDS>();
     else if (NS >= 3 && ahead >= 1) wait_dma_barrier<(NS >= 3 ? 1 : 0) * GLDS>();
     else wait_dma_barrier<0>();
-    if (kt + NS - 1 < nk) stage(kt + NS - 1, wbuf);
-    wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
     const char* s = lds + rbuf * STAGE;
     rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
     const char* sa = s + wm * WM * ROW_BYTES;
     const char* sw = s + A_TILE * NPL + wn * WN * ROW_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = lds_frag(sa, i * 16 + fr, ks * 4 + fq);
-        if (X3) al[i] = lds_frag(sa + A_TILE, i * 16 + fr, ks * 4 + fq);
-      }
+    // Fragment reads are software-pipelined by hand: the ds_read_b128s of k-step ks+1 are issued after the first MFMA
+    // rows of k-step ks and pinned there (sched_barrier: nothing is scheduled across it), so they land under the
+    // remaining rows (the summation order per accumulator is unchanged).  Left alone, the compiler keeps one
+    // A fragment live at a time — read, s_waitcnt lgkmcnt(0), four MFMAs, read, ... — which exposes the full LDS latency
+    // every 64 MFMA cycles (measured: ~2700 cycles per k-tile of a 192x128 tile against 768 cycles of MFMA issue).
+    bf16x8 ah[2][TM], bh[2][TN], al[2][X3 ? TM : 1], bl[2][X3 ? TN : 1];
+    auto read_frags = [&](int ks, int set) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = lds_frag(sw, j * 16 + fr, ks * 4 + fq);
-        if (X3) bl[j] = lds_frag(sw + W_TILE, j * 16 + fr, ks * 4 + fq);
+        bh[set][j] = lds_frag(sw, j * 16 + fr, ks * 4 + fq);
+        if (X3) bl[set][j] = lds_frag(sw + W_TILE, j * 16 + fr, ks * 4 + fq);
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        ah[set][i] = lds_frag(sa, i * 16 + fr, ks * 4 + fq);
+        if (X3) al[set][i] = lds_frag(sa + A_TILE, i * 16 + fr, ks * 4 + fq);
+      }
+    };
+    constexpr int KS = (SER_GEMM_DIAG & 2) ? 0 : 2;
+    if (KS) read_frags(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the refill of the buffer read in the previous iteration is issued while the first fragments are on their way
+    if (kt + NS - 1 < nk) stage(kt + NS - 1, wbuf);
+    wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
+    __builtin_amdgcn_sched_barrier(0);
+    auto mfma_rows = [&](int cur, int i_lo, int i_hi) {
+#pragma unroll
+      for (int i = i_lo; i < i_hi; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if (X3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
         }
+    };
+    constexpr int HEAD = TM >= 3 ? TM / 3 : 1;     // MFMA rows issued before the next k-step's reads go out
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cur = ks & 1;
+      mfma_rows(cur, 0, HEAD);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks + 1 < KS) read_frags(ks + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_rows(cur, HEAD, TM);
     }
   }
 
@@ -192,6 +222,15 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
   // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
   constexpr int LDT = BN + 4;                       // floats; +4 keeps the two half-waves on different banks
   float* tile = (float*)lds;
+  if (SER_GEMM_DIAG & 1) {                          // probe: keep the accumulators alive, store (almost) nothing
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sacc += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sacc == 123456.789f && g.c_f32) g.c_f32[0] = sacc;
+    return;
+  }
   const long long coff = b1 * g.sc1 + b2 * g.sc2;
   const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
   const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
@@ -225,6 +264,10 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], g.act);
     const long long o = coff + (long long)m * g.ldc + n;
+    if (SER_GEMM_DIAG & 8) {
+      if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123456.789f && g.c_hi) g.c_hi[o] = 1;
+      continue;
+    }
     if (vec) {
       if (res) {
         const float* rp = res + (long long)m * g.ldr + n;
@@ -312,18 +355,22 @@ static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
 // LDS stages for the bf16 (single-product) kernels, per tile shape: experiment knob, see ser_launch_gemm_bf16
-static int g_gemm_stages[4] = {2, 3, 2, 2};   // [0] 128x128  [1] 64x128  [2] 64x64  [3] 128x64
+static int g_gemm_stages[7] = {2, 3, 2, 2, 2, 2, 2};   // [0] 128x128  [1] 64x128  [2] 64x64  [3] 128x64  [4] 96x128  [5] 160x128  [6] 192x128
 // measured at BASELINE config 2 (ms/step): {2,2,2,2} 3.906, {2,3,2,2} 3.870, {2,4,2,2} 4.04, {3,3,2,2} 4.45 (96 KB of LDS
-// per 128x128 workgroup leaves one per CU): only the 64x128 tiles (~1.4 workgroups per CU, 48 k-tiles) gain from a
-// third buffer, and little: these GEMMs are bound by LDS traffic (DMA writes + fragment reads), not by DMA latency.
+// per 128x128 workgroup leaves one per CU).  scripts/gemm_phase_probe.py: with two buffers a k-tile costs the DMA round
+// trip (~0.75 us) whatever the MFMA phase takes, so the tall one-round tiles are latency-bound, not LDS- or MFMA-bound.
 extern "C" int ser_debug_set_gemm_stages(int s128, int s64x128, int s64, int s128x64) {
   g_gemm_stages[0] = s128; g_gemm_stages[1] = s64x128; g_gemm_stages[2] = s64; g_gemm_stages[3] = s128x64;
   return 0;
 }
+extern "C" int ser_debug_set_gemm_stages_tall(int s96, int s160, int s192) {
+  g_gemm_stages[4] = s96; g_gemm_stages[5] = s160; g_gemm_stages[6] = s192;
+  return 0;
+}
 template <int BM, int BN>
 static int stages_for() {
-  if (BM != 64 && BM != 128) return 2;
-  const int v = g_gemm_stages[BM == 128 ? (BN == 128 ? 0 : 3) : (BN == 128 ? 1 : 2)];
+  const int idx = BM == 128 ? (BN == 128 ? 0 : 3) : BM == 64 ? (BN == 128 ? 1 : 2) : BM == 96 ? 4 : BM == 160 ? 5 : 6;
+  const int v = g_gemm_stages[idx];
   return v < 2 ? 2 : (v > 4 ? 4 : v);
 }
 
@@ -346,7 +393,7 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<XBM, BN, true>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
   } else {
     const int ns = stages_for<BM, BN>();
-    constexpr bool MULTI = BM == 64 || BM == 128;      // only these shapes are built with more than two LDS buffers
+    constexpr bool MULTI = true;                       // every tile shape is built with two and three LDS buffers
     if (MULTI && ns == 3)
       hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (MULTI ? 3 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
     else if (MULTI && ns == 4 && BM * BN <= 64 * 128)
@@ -381,7 +428,7 @@ int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_
     hipLaunchKernelGGL((gemm_bf16_pair_kernel<XBM, BN, true>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
   } else {
     const int ns = stages_for<BM, BN>();
-    constexpr bool MULTI = BM == 64 || BM == 128;
+    constexpr bool MULTI = true;
     if (MULTI && ns == 3)
       hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (MULTI ? 3 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
     else if (MULTI && ns == 4 && BM * BN <= 64 * 128)
