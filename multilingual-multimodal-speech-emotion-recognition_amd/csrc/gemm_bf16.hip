@@ -13,6 +13,7 @@
 // (16-byte chunk index XOR row&7) is applied to the per-lane SOURCE address and again on the
 // ds_read_b128 side (cdna_hip_programming.md rule 21).  Two LDS stages: the loads of k-tile t+1
 // are in flight while tile t is multiplied; one barrier per k-tile.
+#include <type_traits>
 #include <vector>
 #include "ser_common.h"
 
@@ -24,6 +25,16 @@ namespace {
 // results of a probe build are meaningless.
 #ifndef SER_GEMM_DIAG
 #define SER_GEMM_DIAG 0
+#endif
+// Epilogue form.  0 (product): accumulators -> LDS half tile -> 16-byte row-coalesced stores, two passes.
+// 1 (probe builds only): the MFMA operands are swapped (W fragment first), so a lane's four accumulator registers are
+// four CONSECUTIVE columns of one row and go to global memory straight from registers (8-byte bf16 / 16-byte fp32
+// stores, 32 / 64 contiguous bytes per row and instruction), no LDS pass, no workgroup barriers.  Measured
+// (scripts/gemm_phase_probe.py, profiles/r01_m_gemm_phase_probe.txt): the LDS pass + arithmetic shrink from 4.9 to
+// 1.7 us per 192x128 launch but the narrow stores cost 7.9 instead of 3.6 us; -3 % / +5 % stand-alone depending on the
+// shape and +3.5 % on the overlapped step (3.64 vs 3.52 ms) — not the default.
+#ifndef SER_GEMM_EPI_DIRECT
+#define SER_GEMM_EPI_DIRECT 0
 #endif
 
 constexpr int BK = 64;           // bf16 elements per k-tile = 128 B per row
@@ -71,17 +82,24 @@ SER_DEVFN float apply_act(float v, int act) {
   return v;
 }
 
+template <int ACT>
+SER_DEVFN float act_const(float v) {
+  return ACT == SER_ACT_GELU ? gelu_erf(v) : ACT == SER_ACT_RELU ? fmaxf(v, 0.0f) : v;
+}
+
 template <int BM, int BN, bool X3, int NS = 2>
 struct GemmCfg {
   static constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
   static constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
   static constexpr int STAGE = (A_TILE + W_TILE) * NPL;
   static constexpr int EPI_BYTES = (BM / 2) * (BN + 4) * 4;  // fp32 HALF tile staged for the coalesced epilogue (two passes)
-  static constexpr int LDS_RAW = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
+  static constexpr int LDS_RAW = (SER_GEMM_EPI_DIRECT || NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
   static constexpr int GLDS = (BM / 32 + BN / 32) * NPL;       // LDS-DMA instructions per stage per wave
   // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
   // GEMMs on another stream, and a small workgroup that cannot get LDS waits for a whole GEMM workgroup to retire
   static constexpr int LDS_BYTES = LDS_RAW <= 32 * 1024 ? 34 * 1024 : LDS_RAW;
+  // register budget: where LDS lets two workgroups share a CU, VGPRs + AGPRs must stay within 256 per lane
+  static constexpr int WG_PER_CU = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;
 };
 
 // one output tile; `bid` = tile index inside the (clip, group) batch entry `bz`
@@ -198,11 +216,19 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
       for (int i = i_lo; i < i_hi; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if (X3) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
+          if (SER_GEMM_EPI_DIRECT) {        // D^T: rows of the MFMA = columns n, same products in the same order
+            if (X3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cur][j], al[cur][i], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
+          } else {
+            if (X3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
         }
     };
     constexpr int HEAD = TM >= 3 ? TM / 3 : 1;     // MFMA rows issued before the next k-step's reads go out
@@ -231,6 +257,106 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     if (sacc == 123456.789f && g.c_f32) g.c_f32[0] = sacc;
     return;
   }
+  if (SER_GEMM_EPI_DIRECT) {
+    // swapped-operand C/D map: acc[i][j][r] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + r]
+    const long long coff = b1 * g.sc1 + b2 * g.sc2;
+    const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
+    const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
+    // 4-wide form: four consecutive columns per lane, 8/16-byte accesses; anything ragged or unaligned (never the
+    // case on the path: N, ldc, ldr are multiples of 4) goes element by element
+    const bool al4 = ((g.ldc & 3) == 0) && ((coff & 3) == 0) &&
+                     (!res || (((g.ldr & 3) == 0) && ((((uintptr_t)res) & 15) == 0)));
+    // the residual values of a group of block columns (half the tile; one column for the 160/192-row tiles) are requested
+    // before the first one is used: 2-4 exposed load latencies per tile instead of one per 16x16 block, in at most
+    // 32 registers, so that VGPRs + AGPRs stay <= 256 (two workgroups per CU)
+    constexpr int TNH = TM > 4 ? 1 : (TN >= 2 ? TN / 2 : 1);     // block columns per group
+    constexpr int NG = TN / TNH;
+    float4 rv[TM][TNH];
+    auto prefetch_residual = [&](int jh) {
+      if (!(res && al4)) return;
+#pragma unroll
+      for (int jj = 0; jj < TNH; ++jj)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int n = n0 + wn * WN + (jh * TNH + jj) * 16 + fq * 4, m = m0 + wm * WM + i * 16 + fr;
+          if (m < g.M && n + 3 < g.N) rv[i][jj] = *(const float4*)(res + (long long)m * g.ldr + n);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // one copy of the store code per activation, chosen once (uniform), instead of a switch per element
+    auto epilogue = [&](auto act_tag, auto half_tag) {
+      constexpr int ACT = decltype(act_tag)::value, JH = decltype(half_tag)::value;
+#pragma unroll
+      for (int j = JH * TNH; j < (JH + 1) * TNH; ++j) {
+        const int n = n0 + wn * WN + j * 16 + fq * 4;
+        if (n >= g.N) continue;
+        const bool vec = al4 && (n + 3 < g.N);
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = (bias && n + e < g.N) ? bias[n + e] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = m0 + wm * WM + i * 16 + fr;
+          if (m >= g.M) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_const<ACT>(acc[i][j][e] + bv[e]);
+          const long long o = coff + (long long)m * g.ldc + n;
+          if (SER_GEMM_DIAG & 8) {
+            if (v[0] + v[1] + v[2] + v[3] == 123456.789f && g.c_hi) g.c_hi[o] = 1;
+            continue;
+          }
+          if (vec) {
+            if (res) {
+              const float4 r0 = rv[i][j - JH * TNH];
+              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+            }
+            if (g.c_f32) *(float4*)(g.c_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (g.c_hi) {
+              uint32_t ph[2], pl[2];
+              if (g.c_lo) {
+                split_bf16x2(v[0], v[1], ph[0], pl[0]);
+                split_bf16x2(v[2], v[3], ph[1], pl[1]);
+                *(uint2*)(g.c_lo + o) = make_uint2(pl[0], pl[1]);
+              } else {
+                ph[0] = pack_bf16x2(v[0], v[1]);
+                ph[1] = pack_bf16x2(v[2], v[3]);
+              }
+              *(uint2*)(g.c_hi + o) = make_uint2(ph[0], ph[1]);
+            }
+          } else {
+#pragma unroll 1
+            for (int e = 0; e < 4 && n + e < g.N; ++e) {
+              float x = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
+              if (res) x += res[(long long)m * g.ldr + n + e];
+              if (g.c_f32) g.c_f32[o + e] = x;
+              if (g.c_hi) {
+                bf16_t h, l;
+                split_bf16(x, h, l);
+                g.c_hi[o + e] = h;
+                if (g.c_lo) g.c_lo[o + e] = l;
+              }
+            }
+          }
+        }
+      }
+    };
+    auto half = [&](auto half_tag) {
+      prefetch_residual(decltype(half_tag)::value);
+      if (g.act == SER_ACT_GELU) epilogue(std::integral_constant<int, SER_ACT_GELU>{}, half_tag);
+      else if (g.act == SER_ACT_RELU) epilogue(std::integral_constant<int, SER_ACT_RELU>{}, half_tag);
+      else epilogue(std::integral_constant<int, SER_ACT_NONE>{}, half_tag);
+    };
+    static_assert(NG == 1 || NG == 2 || NG == 4, "epilogue groups");
+    half(std::integral_constant<int, 0>{});
+    if constexpr (NG > 1) half(std::integral_constant<int, 1>{});
+    if constexpr (NG > 2) {
+      half(std::integral_constant<int, 2>{});
+      half(std::integral_constant<int, 3>{});
+    }
+    return;
+  }
+
   const long long coff = b1 * g.sc1 + b2 * g.sc2;
   const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
   const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
@@ -319,7 +445,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 // ever waits in the dispatcher's queue, so the small head kernels of the other stream are placed as soon as they
 // arrive instead of behind this kernel's not-yet-dispatched workgroups.
 template <int BM, int BN, bool X3, int NS = 2>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
+__global__ __launch_bounds__(256, (GemmCfg<BM, BN, X3, NS>::WG_PER_CU)) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
   __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3, NS>::LDS_BYTES];
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
     gemm_tile<BM, BN, X3, NS>(g, w % tiles, w / tiles, lds);
@@ -331,7 +457,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(const SerGemmArgs g, 
 // other): the tiles of the small problem come first in the grid, so they start at once and ride along with the
 // large one instead of queueing, launch after launch, on a second stream behind it.
 template <int BM, int BN, bool X3, int NS = 2>
-__global__ __launch_bounds__(256) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
+__global__ __launch_bounds__(256, (GemmCfg<BM, BN, X3, NS>::WG_PER_CU)) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
                                                              const int tiles0, const int tiles1) {
   __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3, NS>::LDS_BYTES];
   // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches

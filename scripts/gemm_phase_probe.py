@@ -17,7 +17,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "multilingual-multimodal-speech-emotion-recognition_amd", "csrc")
 DIAG = os.path.join(ROOT, "scripts", "diag")
-VARIANTS = {0: "full", 1: "no epilogue", 2: "no reads/MFMA", 4: "no staging", 6: "skeleton", 7: "floor", 14: "skeleton, no stores"}
+VARIANTS = {0: "full", 1: "no epilogue", 2: "no reads/MFMA", 4: "no staging", 6: "skeleton", 7: "floor", 14: "skeleton, no stores",
+            "direct": "full, register-direct epilogue"}
 
 
 def build():
@@ -28,8 +29,9 @@ def build():
         if d == 0:
             continue
         obj = os.path.join(DIAG, f"gemm_diag{d}.o")
+        define = "-DSER_GEMM_EPI_DIRECT=1" if d == "direct" else f"-DSER_GEMM_DIAG={d}"
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17",
-                               f"-DSER_GEMM_DIAG={d}", "-c", os.path.join(CSRC, "gemm_bf16.hip"), "-o", obj])
+                               define, "-c", os.path.join(CSRC, "gemm_bf16.hip"), "-o", obj])
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                                os.path.join(DIAG, f"libser_diag{d}.so"), obj] + others)
 
