@@ -164,3 +164,21 @@ def test_synthetic_dataset_shapes():
     ds = SyntheticSERDataset(5, seconds=1.0, num_labels=4)
     w, txt, y = ds[3]
     assert w.shape == (16000,) and len(txt.split()) == 30 and 0 <= y < 4
+
+
+def test_bench_contract_pieces_without_a_gpu():
+    """bench.py: defaults finish in minutes at N=1, the synthetic batch has BASELINE config 2's shape, and without a GPU
+    the script refuses to run (there is no CPU fallback of the product path)."""
+    import subprocess
+    import sys
+    import bench
+    wave, ids, mask, labels = bench.synth_batch(16, 4.0, 32, 250002, 4, seed=1)
+    assert wave.shape == (16, 64000) and ids.shape == (16, 32) and mask.shape == (16, 32) and labels.shape == (16,)
+    assert int(ids[:, 0].max()) == 0 and int(ids[:, -1].min()) == 2 and int(labels.max()) < 4
+    wc, xc = bench.hf_configs()
+    assert (wc.hidden_size, wc.num_hidden_layers, xc.hidden_size, xc.num_hidden_layers) == (768, 12, 768, 12)
+    if not torch.cuda.is_available():
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr and not r.stdout.strip()
