@@ -7,12 +7,14 @@
 // carries ~2^-16 relative error per product instead of bf16's 2^-8; in fast mode only the hi
 // planes are read.
 //
-// Structure: BMxBN output tile per 256-thread workgroup (4 waves as 2x2), BK = 64.
+// Structure: BMxBN output tile per 256-thread workgroup (4 waves as 2x2; BM = 64...192, BN = 128 or 64), BK = 64.
 // Global -> LDS goes through global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): one wave
 // instruction moves 8 rows x 128 B.  The LDS image is lane-linear, so the bank-conflict swizzle
 // (16-byte chunk index XOR row&7) is applied to the per-lane SOURCE address and again on the
-// ds_read_b128 side (cdna_hip_programming.md rule 21).  Two LDS stages: the loads of k-tile t+1
-// are in flight while tile t is multiplied; one barrier per k-tile.
+// ds_read_b128 side (cdna_hip_programming.md rule 21).  NS LDS buffers (2, or 3 where measured to pay): the loads of
+// k-tiles t+1 .. t+NS-1 are in flight while tile t is multiplied; one counted s_waitcnt vmcnt + s_barrier per k-tile.
+// Inside a k-tile the fragment reads of k-step 1 are issued under the MFMAs of k-step 0 (pinned with sched_barrier).
+// Epilogue: accumulators -> LDS half tile -> 16-byte row-coalesced stores with bias / GELU / residual / bf16 plane split.
 #include <type_traits>
 #include <vector>
 #include "ser_common.h"
