@@ -281,9 +281,11 @@ def xlmr_forward(sd: SD, ids: Tensor, attn_mask: Tensor, cfg) -> Tensor:
     """XLMRobertaModel.forward (eval).  ids [B,S] int64, attn_mask [B,S] 1/0."""
     eps = cfg["eps"]
     pos = xlmr_position_ids(ids, cfg["pad_id"])
-    e = (sd["embeddings.word_embeddings.weight"][ids]
+    # nn.Embedding(padding_idx=pad) for words and positions (hf modeling_xlm_roberta.py:75-95): same values, and the pad
+    # row receives no gradient when the encoder is unfrozen
+    e = (F.embedding(ids, sd["embeddings.word_embeddings.weight"], padding_idx=cfg["pad_id"])
          + sd["embeddings.token_type_embeddings.weight"][0]
-         + sd["embeddings.position_embeddings.weight"][pos])
+         + F.embedding(pos, sd["embeddings.position_embeddings.weight"], padding_idx=cfg["pad_id"]))
     h = layer_norm(e, sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], eps)
     key_bias = torch.zeros(attn_mask.shape, dtype=torch.float32)
     key_bias = key_bias.masked_fill(attn_mask == 0, float("-inf"))

@@ -174,3 +174,35 @@ def test_cpu_train_step_applies_the_dropout_plan_deterministically():
     off, a, b, c = losses(None), losses(7), losses(7), losses(8)
     assert a == b and a != c and a != off
     assert all(np.isfinite(x) for x in off + a + c)
+
+
+def _check_grads(p, gr):
+    """Per tensor: max-abs-err <= 2e-4 * max|grad of the tensor| + 2e-6 * max|grad| over the model (the floor covers
+    gradients that are zero in exact arithmetic, e.g. the key bias of a softmax attention)."""
+    assert gr, "fixture holds no gradients"
+    gmax = max(float(g.abs().max()) for g in gr.values())
+    for k, g in gr.items():
+        assert p[k].grad is not None, f"no gradient reached {k}"
+        err = float((p[k].grad - g).abs().max())
+        assert err <= 2e-4 * float(g.abs().max()) + 2e-6 * gmax, f"{k}: max-abs-err {err:.2e} (max|grad| {float(g.abs().max()):.2e})"
+
+
+def test_audio_encoder_backward_unfrozen():
+    """BASELINE config 3 (`freeze_base=False`, reference audio_encoder.py:9-17): autograd through the oracle's Wav2Vec2
+    restatement reproduces the reference's gradients for every encoder and adapter parameter."""
+    sd, _, r = split_fixture(load_npz("audio_encoder.npz"))
+    _, gr, rg = split_fixture(load_npz("audio_encoder_grads.npz"))
+    p = _leafs(sd)
+    seq, _ = O.audio_encoder_forward(p, [t(r["wave0"]), t(r["wave1"])], cfg_of(r))
+    (seq * t(rg["g_out"])).sum().backward()
+    _check_grads(p, gr)
+
+
+def test_text_encoder_backward_unfrozen():
+    """BASELINE config 3 (reference text_encoder.py:8-15): same for XLM-R, embeddings included."""
+    sd, _, r = split_fixture(load_npz("text_encoder.npz"))
+    _, gr, rg = split_fixture(load_npz("text_encoder_grads.npz"))
+    p = _leafs(sd)
+    seq, _ = O.text_encoder_forward(p, t(r["input_ids"]), t(r["attention_mask"]), cfg_of(r))
+    (seq * t(rg["g_out"])).sum().backward()
+    _check_grads(p, gr)
