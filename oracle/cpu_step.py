@@ -26,11 +26,14 @@ def _classifier_group(name):
 
 class OracleTrainer:
     def __init__(self, sds, a_cfg, t_cfg, num_layers=35, heads=8, num_labels=4, lr=1e-4, dropout_seed=None,
-                 p_cross=0.1, p_fusion=0.1, p_classifier=0.15):
+                 p_cross=0.1, p_fusion=0.1, p_classifier=0.15, train_encoders=False):
         """dropout_seed: when given, every step applies the head's training-mode dropout with the masks of the build's
         generator (state = seed + step), i.e. the CPU baseline times the same train-mode step the HIP path runs."""
         self.a_cfg, self.t_cfg, self.L, self.heads, self.C, self.lr = a_cfg, t_cfg, num_layers, heads, num_labels, lr
         self.dropout_seed, self.p = dropout_seed, (p_cross, p_fusion, p_classifier)
+        # BASELINE config 3 (reference `freeze_base=False`): the encoders receive gradients and AdamW updates in their
+        # groups (lr x 0.1); their own training-mode noise (HF dropout / SpecAugment / LayerDrop) is not modelled
+        self.train_encoders = train_encoders
         self.sds = {k: {n: v.detach().clone().float() if v.dtype.is_floating_point else v.clone() for n, v in sd.items()}
                     for k, sd in sds.items()}
         self.state = {}
@@ -39,8 +42,8 @@ class OracleTrainer:
     def _leafs(self):
         for k, sd in self.sds.items():
             for n, v in sd.items():
-                train = v.dtype.is_floating_point and not n.startswith("encoder.") and not n.startswith("weibull") \
-                    and n != "activation_vectors"
+                train = v.dtype.is_floating_point and (self.train_encoders or not n.startswith("encoder.")) \
+                    and not n.startswith("weibull") and n != "activation_vectors"
                 v.requires_grad_(train)
                 v.grad = None
 
@@ -50,7 +53,7 @@ class OracleTrainer:
 
     def step(self, waves, ids, mask, labels):
         self._leafs()
-        with torch.no_grad():   # frozen encoders
+        with torch.set_grad_enabled(self.train_encoders):   # frozen encoders unless config 3
             enc_a = O.wav2vec2_forward(O.sub(self.sds["audio_encoder"], "encoder."),
                                        torch.stack([O.normalise_waveform(w) for w in waves]), self.a_cfg)
             enc_t = O.xlmr_forward(O.sub(self.sds["text_encoder"], "encoder."), ids, mask, self.t_cfg)

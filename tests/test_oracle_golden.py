@@ -206,3 +206,26 @@ def test_text_encoder_backward_unfrozen():
     seq, _ = O.text_encoder_forward(p, t(r["input_ids"]), t(r["attention_mask"]), cfg_of(r))
     (seq * t(rg["g_out"])).sum().backward()
     _check_grads(p, gr)
+
+
+def test_cpu_train_step_with_unfrozen_encoders_updates_them():
+    """oracle/cpu_step.py with train_encoders=True (BASELINE config 3): encoder parameters move, by their group's
+    learning rate (0.1 x), and stay put when frozen."""
+    import __graft_entry__ as ge
+    from oracle.cpu_step import OracleTrainer
+    sysm, wc, xc = ge._small_system("cpu")
+    sds = {k: {n: v.detach() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    g = torch.Generator().manual_seed(2)
+    wave, ids = 0.1 * torch.randn(2, 4000, generator=g), torch.randint(4, 1000, (2, 8), generator=g)
+    mask, labels = torch.ones(2, 8), torch.tensor([0, 3])
+    key = "encoder.encoder.layers.0.attention.q_proj.weight"
+    moved = {}
+    for flag in (False, True):
+        tr = OracleTrainer(sds, a_cfg, t_cfg, num_layers=3, heads=2, num_labels=4, lr=1e-3, train_encoders=flag)
+        before = tr.sds["audio_encoder"][key].clone()
+        loss, _ = tr.step(list(wave), ids, mask, labels)
+        assert np.isfinite(loss)
+        moved[flag] = float((tr.sds["audio_encoder"][key].detach() - before).abs().max())
+    assert moved[False] == 0.0
+    assert 0.0 < moved[True] <= 1.01e-4 + 1e-3 * 0.025 * 1e-4 * 10       # one AdamW step: |delta| <= lr x 0.1 (+ decay)
