@@ -82,10 +82,18 @@ class OracleTrainer:
         return loss.item(), logits.detach()
 
 
-def time_steps(trainer, waves, ids, mask, labels, warmup=1, steps=2):
+def time_steps(trainer, waves, ids, mask, labels, warmup=2, steps=5, budget_s=None):
+    """Per-step wall times (seconds) of `steps` training steps after `warmup` untimed ones (BASELINE.md section 2:
+    2 + >= 5, report the median).  With `budget_s` the timed loop stops early once that much time has been spent,
+    but never before three steps."""
+    t_all = time.perf_counter()
     for _ in range(warmup):
         trainer.step(waves, ids, mask, labels)
-    t0 = time.perf_counter()
+    out = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         trainer.step(waves, ids, mask, labels)
-    return (time.perf_counter() - t0) / steps
+        out.append(time.perf_counter() - t0)
+        if budget_s is not None and len(out) >= 3 and time.perf_counter() - t_all > budget_s:
+            break
+    return out
