@@ -53,13 +53,21 @@ int ser_stream_destroy(void* stream);
  * op-level entry points (used by the parity tests and composed by the module-level calls)
  * ------------------------------------------------------------------------------------------- */
 
-/* x[n] fp32 -> hi[n], lo[n] bf16 planes (lo may be NULL). */
+/* Split planes come in two layouts.  PLANAR: hi[n] and lo[n] are separate arrays.  INTERLEAVED: one array of 2 n
+ * elements in which every run of 32 hi values is followed by its 32 lo values ([hi 0..31 | lo 0..31 | hi 32..63 | ...]);
+ * a 128-byte line of a K-contiguous row then holds both planes of 32 values of k, which lets the three-product GEMM
+ * stage exactly the bytes of a one-product k-tile.  An entry point recognises the interleaved layout by
+ * lo == hi + 32 (elements): pass the array as `hi` and `hi + 32` as `lo`.  Row lengths must be multiples of 32.
+ * Every (hi, lo) argument of the encoder entry points below accepts both layouts; A and W of a GEMM must agree. */
+
+/* x[n] fp32 -> hi[n], lo[n] bf16 planes (lo may be NULL; interleaved when lo == hi + 32, then n % 32 == 0). */
 int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long long n, void* stream);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, split-bf16 operands, fp32 accumulate.
  * Replaces every torch.nn.Linear / Conv1d-as-GEMM inside the frozen encoders
  * (hf: wav2vec2/modeling_wav2vec2.py:254-272,429-435,500-572; xlm_roberta/modeling_xlm_roberta.py:211-250,336-398).
- * K % 64 == 0, lda/ldw % 8 == 0.  Any of c_f32 / (c_hi,c_lo) may be NULL. */
+ * K % 64 == 0, lda/ldw % 8 == 0 (interleaved operands: K, lda, ldw % 32 == 0; lda/ldw/ldc count LOGICAL elements).
+ * Any of c_f32 / (c_hi,c_lo) may be NULL; (c_hi, c_lo = c_hi + 32) writes the interleaved layout. */
 int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi,
                      const uint16_t* w_lo, int ldw, int M, int N, int K, const float* bias, int act,
                      const float* residual, int ldr, float* c_f32, uint16_t* c_hi, uint16_t* c_lo,
@@ -331,6 +339,11 @@ int ser_dropout(const float* x, long long n, const void* state, unsigned site, f
  * hyper (device) = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; effective lr = hyper[0] * lr_mult. */
 int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float lr_mult,
               float weight_decay, float beta1, float beta2, float eps, void* stream);
+/* Measured tile height (64..192 rows) for the BN = 128 encoder GEMMs of shape (rows_total, N, K), recorded by the
+ * engines' one-time timing pass; `three_products` selects the table of the interleaved three-product mode.  Speed only. */
+int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm);
+int ser_gemm_tile_hint_mode(long long rows_total, int N, int K, int three_products, int bm);
+
 /* the same update for many flat segments (the ten optimizer groups of train.py:72-83 x their buckets) in one launch per
  * 16 segments; ptrs = host array {p, g, m, v} per segment, n / lr_mult / weight_decay = host arrays per segment */
 int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay, int nseg,

@@ -23,8 +23,15 @@ class _Keep:
         self.t.append(x)
         return x.data_ptr()
 
-    def split(self, x, dev, want_lo):
+    def split(self, x, dev, want_lo, planar=False):
+        """Kernel-ready weight [N, K]: the hi plane alone (one-product mode), or both planes — interleaved in groups of
+        32 along K (what the three-product GEMM reads, csrc/ser_common.h) unless `planar` (positional conv)."""
         x = x.detach().to(device=dev, dtype=torch.float32).contiguous()
+        if want_lo and not planar:
+            w = L.split_bf16_il(x)
+            self.t.append(w)
+            hi, lo = L.il_ptrs(w)
+            return L.SplitW(hi, lo)
         hi, lo = L.split_bf16(x, want_lo)
         self.t += [hi, lo]
         return L.SplitW(hi.data_ptr(), lo.data_ptr() if lo is not None else None)
@@ -115,7 +122,7 @@ class Wav2Vec2Engine:
         G = self.cfg.pos_groups
         H, Cg, K = pw.shape
         pw = pw.reshape(G, H // G, Cg, K).permute(0, 1, 3, 2).reshape(G * (H // G), K * Cg)   # [g][n][j][c]
-        w.pos_w = keep.split(pw, dev, want_lo)
+        w.pos_w = keep.split(pw, dev, want_lo, planar=True)   # Toeplitz view, row step 48 elements: planar planes
         w.pos_b = keep.f32(sd["encoder.pos_conv_embed.conv.bias"], dev)
         w.enc_ln_g = keep.f32(sd["encoder.layer_norm.weight"], dev)
         w.enc_ln_b = keep.f32(sd["encoder.layer_norm.bias"], dev)
@@ -200,26 +207,30 @@ _TUNED = set()
 TILE_HEIGHTS = (64, 96, 128, 160, 192)
 
 
-def tune_gemm_shapes(shapes, device, reps=8):
-    """shapes: iterable of (rows_total, N, K) of bf16 NT GEMMs with N >= 128."""
+def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
+    """shapes: iterable of (rows_total, N, K) of bf16 NT GEMMs with N >= 128; `three_products`: the interleaved
+    three-product mode (its own table: a k-tile carries 1.5x the MFMA work of the one-product kernel's)."""
     if torch.cuda.is_current_stream_capturing():
         return
+    pm = 2 if three_products else 1
     for rows, N, K in shapes:
-        key = (int(rows), int(N), int(K), torch.device(device).index)
+        key = (int(rows), int(N), int(K), pm, torch.device(device).index)
         if key in _TUNED or N < 128 or rows <= 64:
             continue
         _TUNED.add(key)
-        a = torch.zeros(rows, K, dtype=torch.bfloat16, device=device)
-        w = torch.zeros(N, K, dtype=torch.bfloat16, device=device)
-        c = torch.empty(rows, N, dtype=torch.bfloat16, device=device)
+        g = torch.Generator(device="cpu").manual_seed(0)     # random operands: zeros flatter the clock (DVFS)
+        a = (torch.randn(rows, K * pm, generator=g) * 0.5).to(device=device, dtype=torch.bfloat16)
+        w = (torch.randn(N, K * pm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
+        c = torch.empty(rows, N * pm, dtype=torch.bfloat16, device=device)
+        lo = (lambda t: t.data_ptr() + 2 * L.IL_GROUP) if three_products else (lambda t: None)
         best, best_ms = 0, float("inf")
         try:
             for bm in TILE_HEIGHTS:
                 L.lib.ser_debug_set_gemm_bm(bm)
 
                 def run():
-                    L.check(L.lib.ser_gemm_bf16_nt(a.data_ptr(), None, K, w.data_ptr(), None, K, rows, N, K, None, L.ACT_NONE, None,
-                                                   0, None, c.data_ptr(), None, N, L.stream_ptr()), "ser_gemm_bf16_nt")
+                    L.check(L.lib.ser_gemm_bf16_nt(a.data_ptr(), lo(a), K, w.data_ptr(), lo(w), K, rows, N, K, None, L.ACT_NONE, None,
+                                                   0, None, c.data_ptr(), lo(c), N, L.stream_ptr()), "ser_gemm_bf16_nt")
                 run(); run()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -232,7 +243,7 @@ def tune_gemm_shapes(shapes, device, reps=8):
                     best, best_ms = bm, ms
         finally:
             L.lib.ser_debug_set_gemm_bm(0)
-        L.lib.ser_gemm_tile_hint(rows, N, K, best)
+        L.lib.ser_gemm_tile_hint_mode(rows, N, K, 1 if three_products else 0, best)
 
 
 def _w2v_gemm_shapes(cfg, B, T, extra_rows=0):
@@ -268,8 +279,8 @@ def forward_pair(audio_engine, text_engine, wave, ids, attn_mask):
     if na == 0 or nt == 0:
         L.check(-1, "ser_*_workspace_bytes")
     wsa, wst = a.ws.get(na, wave.device), t.ws.get(nt, ids.device)
-    if a.prec == L.PREC_BF16 and a.cfg.layers == t.cfg.layers and a.cfg.hidden == t.cfg.hidden:
-        tune_gemm_shapes(_w2v_gemm_shapes(a.cfg, B, T, extra_rows=Bt * St), wave.device)
+    if a.cfg.layers == t.cfg.layers and a.cfg.hidden == t.cfg.hidden:
+        tune_gemm_shapes(_w2v_gemm_shapes(a.cfg, B, T, extra_rows=Bt * St), wave.device, three_products=a.prec == L.PREC_BF16X3)
     out_a = torch.empty(B, Sa, a.hidden, dtype=torch.float32, device=wave.device)
     out_t = torch.empty(Bt, St, t.hidden, dtype=torch.float32, device=ids.device)
     L.check(L.lib.ser_encoders_forward(C.byref(a.cfg), C.byref(a.w), wave.data_ptr(), B, T, C.byref(t.cfg), C.byref(t.w),

@@ -128,6 +128,46 @@ def split_bf16(x, want_lo=True):
     return hi, lo
 
 
+IL_GROUP = 32        # interleaved split planes: [hi 0..31 | lo 0..31 | hi 32..63 | ...] (csrc/ser_common.h)
+
+
+def split_bf16_il(x):
+    """fp32 device tensor [..., D] (D % 32 == 0) -> ONE bf16 tensor [..., 2 D] holding both planes interleaved in groups
+    of 32.  The library recognises the layout by `lo == hi + 32 elements` (see `il_ptrs`)."""
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and x.shape[-1] % IL_GROUP == 0
+    out = torch.empty(x.shape[:-1] + (2 * x.shape[-1],), dtype=torch.bfloat16, device=x.device)
+    check(lib.ser_split_bf16(ptr(x), out.data_ptr(), out.data_ptr() + 2 * IL_GROUP, x.numel(), stream_ptr()), "ser_split_bf16")
+    return out
+
+
+def il_ptrs(t):
+    """(hi, lo) pointer pair of an interleaved tensor."""
+    return t.data_ptr(), t.data_ptr() + 2 * IL_GROUP
+
+
+def il_planes(t):
+    """Interleaved tensor [..., 2 D] -> (hi, lo) views [..., D] (tests)."""
+    v = t.reshape(t.shape[:-1] + (t.shape[-1] // (2 * IL_GROUP), 2, IL_GROUP))
+    D = t.shape[-1] // 2
+    return v[..., 0, :].reshape(t.shape[:-1] + (D,)), v[..., 1, :].reshape(t.shape[:-1] + (D,))
+
+
+def gemm_bf16x3_il(a_il, w_il, bias=None, act=ACT_NONE, residual=None, out_f32=True, out_split=False):
+    """Three-product NT GEMM on interleaved planes: a_il [M, 2K], w_il [N, 2K] -> (c fp32 [M,N] or None, c_il [M,2N] or None)."""
+    M, K = a_il.shape[0], a_il.shape[1] // 2
+    N = w_il.shape[0]
+    dev = a_il.device
+    c = torch.empty(M, N, dtype=torch.float32, device=dev) if out_f32 else None
+    ci = torch.empty(M, 2 * N, dtype=torch.bfloat16, device=dev) if out_split else None
+    ah, al = il_ptrs(a_il)
+    wh, wl = il_ptrs(w_il)
+    ch, cl = il_ptrs(ci) if ci is not None else (None, None)
+    check(lib.ser_gemm_bf16_nt(ah, al, K, wh, wl, K, M, N, K, ptr(bias), act, ptr(residual), N, ptr(c), ch, cl, N, stream_ptr()),
+          "ser_gemm_bf16_nt")
+    return c, ci
+
+
 def gemm_bf16_nt(a_hi, a_lo, w_hi, w_lo, bias=None, act=ACT_NONE, residual=None, out_f32=True, out_split=False):
     M, K = a_hi.shape
     N = w_hi.shape[0]
@@ -174,6 +214,7 @@ _sig("ser_add_noise_snr", i32, vp, i32, i32, vp, C.c_ulonglong, vp, vp, vp)
 _sig("ser_dropout", i32, vp, C.c_longlong, vp, C.c_uint, f32, vp, vp)
 _sig("ser_adamw_multi", i32, vp, vp, vp, vp, i32, vp, f32, f32, f32, vp)
 _sig("ser_gemm_tile_hint", i32, C.c_longlong, i32, i32, i32)
+_sig("ser_gemm_tile_hint_mode", i32, C.c_longlong, i32, i32, i32, i32)
 _sig("ser_debug_set_gemm_bm", i32, i32)
 _sig("ser_stack_supported", i32, i32, i32, i32)
 _sig("ser_stack_scratch_bytes", sz, i32)

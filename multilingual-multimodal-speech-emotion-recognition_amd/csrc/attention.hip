@@ -44,6 +44,9 @@ SER_DEVFN void attn_body(const AttnProb& P, const int bx, const int head, const 
   const int q0 = bx * 64 + wave * 16;
   const long long ld = 3LL * H;
   const bf16_t* plane[2] = {qkv_hi, qkv_lo};
+  // interleaved planes (lo == hi + 32, ser_common.h): flat element offsets map by ser_il_off; every access below is a
+  // run of 8 elements inside one 32-group, so it stays one 16-byte access
+  const bool il_in = X3 && ser_is_il(qkv_hi, qkv_lo), il_out = X3 && ser_is_il(ctx_hi, ctx_lo);
 
   // Q fragments straight from global: row q0+fr, d = ks*32 + fq*8 .. +8
   bf16x8 qh[2], ql[2];
@@ -53,8 +56,9 @@ SER_DEVFN void attn_body(const AttnProb& P, const int bx, const int head, const 
     const long long base = ((long long)b * S + qr) * ld + head * HD;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      qh[ks] = *(const bf16x8*)(qkv_hi + base + ks * 32 + fq * 8);
-      if (X3) ql[ks] = *(const bf16x8*)(qkv_lo + base + ks * 32 + fq * 8);
+      const long long e = il_in ? ser_il_off(base + ks * 32 + fq * 8) : base + ks * 32 + fq * 8;
+      qh[ks] = *(const bf16x8*)(qkv_hi + e);
+      if (X3) ql[ks] = *(const bf16x8*)(qkv_lo + e);
     }
   }
 
@@ -76,9 +80,9 @@ SER_DEVFN void attn_body(const AttnProb& P, const int bx, const int head, const 
         int kg = kc * KC + key;
         kg = kg < S ? kg : S - 1;
         const long long rb = ((long long)b * S + kg) * ld + head * HD + ch * 8;
-        const bf16x8 kv = *(const bf16x8*)(plane[p] + rb + H);
+        const bf16x8 kv = *(const bf16x8*)(plane[p] + (il_in ? ser_il_off(rb + H) : rb + H));
         *(bf16x8*)(Ks + p * TILE + tile_off(key, ch)) = kv;
-        const bf16x8 vv = *(const bf16x8*)(plane[p] + rb + 2 * H);
+        const bf16x8 vv = *(const bf16x8*)(plane[p] + (il_in ? ser_il_off(rb + 2 * H) : rb + 2 * H));
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int d = ch * 8 + e;
@@ -179,7 +183,8 @@ SER_DEVFN void attn_body(const AttnProb& P, const int bx, const int head, const 
     const float inv = l[r] > 0.f ? 1.0f / l[r] : 0.f;
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) {
-      const long long off = ((long long)b * S + q) * H + head * HD + jd * 16 + fr;
+      long long off = ((long long)b * S + q) * H + head * HD + jd * 16 + fr;
+      if (il_out) off = ser_il_off(off);
       bf16_t h, lo_;
       split_bf16(o[jd][r] * inv, h, lo_);
       ctx_hi[off] = h;
@@ -187,6 +192,244 @@ SER_DEVFN void attn_body(const AttnProb& P, const int bx, const int head, const 
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (S <= 224: every clip length of the benchmark configs except the 10 s stress case): ONE workgroup of
+// 8 waves per (clip, head) keeps all keys and values of the head in LDS, staged once, in the row order they have in
+// global memory (no transposed copy, no per-query-block restaging).  Each wave owns 16-query blocks:
+//   * scores are computed SWAPPED, S^T = K . Q^T (A = K fragment from LDS, B = Q fragment from global), so a lane holds
+//     scores of ONE query (q = lane & 15) for keys 16 jb + 4 (lane >> 4) + r: the softmax of a row is lane-local apart
+//     from two cross-lane steps over the four lane groups, and all NKB x 4 scores of the row stay in registers (exact
+//     two-pass softmax, no online rescaling);
+//   * P never goes through LDS: the contraction index of P.V may be any permutation of the keys as long as both
+//     operands use it, so the lane's own eight probabilities of key blocks 2 ks and 2 ks + 1 ARE its A fragment for
+//     k-step ks, and the matching V fragment is fetched by two ds_read_b64_tr_b16 (hardware transpose, gfx950) of the
+//     4-key x 16-column blocks at keys 16 (2 ks [+ 1]) + 4 g from the row-major V image;
+//   * the output block goes through a per-wave LDS tile and leaves as whole 128 / 256-byte rows.
+// LDS rows are 128 B (one plane) or 256 B (interleaved hi / lo, the global layout); the 16-byte chunk index is XORed with
+// row & 7 (resp. (row & 7) << 1), which makes the ds_read_b128 K reads and the transposed V reads conflict-free.
+constexpr int SA_MAXKEYS = 224, SA_NKB = SA_MAXKEYS / 16, SA_WAVES = 8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <bool X3>
+struct SaCfg {
+  static constexpr int RB = X3 ? 256 : 128;                      // bytes per key row in LDS
+  static constexpr int CH = RB / 16;
+  static constexpr int LDS_BYTES = 2 * SA_MAXKEYS * RB + 1024 + SA_WAVES * 16 * RB;
+};
+template <bool X3>
+SER_DEVFN int sa_off(int row, int ch) { return row * SaCfg<X3>::RB + ((ch ^ (X3 ? ((row & 7) << 1) : (row & 7))) << 4); }
+// chunk of (plane p, 8-element d-chunk dc = d >> 3) inside a row
+template <bool X3>
+SER_DEVFN int sa_chunk(int p, int dc) { return X3 ? ((dc >> 2) << 3) + (p << 2) + (dc & 3) : dc; }
+
+template <bool X3>
+SER_DEVFN void attn_small_body(const AttnProb& P, const int head, const int b, char* lds) {
+  constexpr int RB = SaCfg<X3>::RB, CH = SaCfg<X3>::CH;
+  const int S = P.S, H = P.H;
+  const int nkb = (S + 15) >> 4;                 // 16-key (and 16-query) blocks
+  const int nks = (nkb + 1) >> 1;                // 32-key k-steps of P.V; rows up to 32 nks are staged (zeros beyond S)
+  char* Ks = lds;
+  char* Vs = lds + SA_MAXKEYS * RB;
+  float* kbias = (float*)(lds + 2 * SA_MAXKEYS * RB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* Os = lds + 2 * SA_MAXKEYS * RB + 1024 + wave * 16 * RB;
+  const int fr = lane & 15, fq = lane >> 4;
+  const long long ld = 3LL * H;
+  const bool il_in = X3 && ser_is_il(P.qkv_hi, P.qkv_lo), il_out = X3 && ser_is_il(P.ctx_hi, P.ctx_lo);
+  (void)il_in;
+
+  // ---- stage K and V rows of this (clip, head): row = key, chunks in global order
+  const int nrows = nks * 32;
+  for (int idx = tid; idx < nrows * CH; idx += SA_WAVES * 64) {
+    const int row = idx / CH, c = idx % CH;
+    bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < S) {
+      const long long base = ((long long)b * S + row) * ld + head * HD;          // logical element offset of Q; K at +H, V at +2H
+      if (X3) {       // interleaved: the head's 64 values are 128 contiguous physical elements [hi 32 | lo 32 | hi 32 | lo 32]
+        kv = *(const bf16x8*)(P.qkv_hi + ser_il_off(base + H) + c * 8);
+        vv = *(const bf16x8*)(P.qkv_hi + ser_il_off(base + 2 * H) + c * 8);
+      } else {
+        kv = *(const bf16x8*)(P.qkv_hi + base + H + c * 8);
+        vv = *(const bf16x8*)(P.qkv_hi + base + 2 * H + c * 8);
+      }
+    }
+    *(bf16x8*)(Ks + sa_off<X3>(row, c)) = kv;
+    *(bf16x8*)(Vs + sa_off<X3>(row, c)) = vv;
+  }
+  for (int k = tid; k < 256; k += SA_WAVES * 64) {
+    bool ok = k < S;
+    if (ok && P.key_mask) ok = P.key_mask[(long long)b * S + k] != 0.f;
+    kbias[k] = ok ? 0.f : -INFINITY;
+  }
+  __syncthreads();
+
+  for (int qb = wave; qb < nkb; qb += SA_WAVES) {
+    // Q fragments (B operand of the swapped product): query qb*16 + fr, d = ks*32 + fq*8 .. +8
+    bf16x8 qh[2], ql[2];
+    {
+      int qr = qb * 16 + fr;
+      qr = qr < S ? qr : S - 1;
+      const long long base = ((long long)b * S + qr) * ld + head * HD;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (X3) {
+          const long long e = ser_il_off(base + ks * 32 + fq * 8);
+          qh[ks] = *(const bf16x8*)(P.qkv_hi + e);
+          ql[ks] = *(const bf16x8*)(P.qkv_hi + e + SER_IL_GROUP);
+        } else {
+          qh[ks] = *(const bf16x8*)(P.qkv_hi + base + ks * 32 + fq * 8);
+        }
+      }
+    }
+    // ---- scores^T: sc[jb][r] = <K[16 jb + 4 fq + r], Q[qb*16 + fr]>
+    f32x4 sc[SA_NKB];
+#pragma unroll
+    for (int jb = 0; jb < SA_NKB; ++jb) {
+      sc[jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (jb < nkb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 kh = *(const bf16x8*)(Ks + sa_off<X3>(jb * 16 + fr, sa_chunk<X3>(0, ks * 4 + fq)));
+          if (X3) {
+            const bf16x8 kl = *(const bf16x8*)(Ks + sa_off<X3>(jb * 16 + fr, sa_chunk<X3>(1, ks * 4 + fq)));
+            sc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], sc[jb], 0, 0, 0);
+            sc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], sc[jb], 0, 0, 0);
+          }
+          sc[jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], sc[jb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- softmax of row q = fr over all keys: lane-local over (jb, r), then over the four lane groups
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < SA_NKB; ++jb)
+      if (jb < nkb) {
+        const float4 kb4 = *(const float4*)(kbias + jb * 16 + fq * 4);
+        sc[jb][0] = sc[jb][0] * 0.125f + kb4.x;
+        sc[jb][1] = sc[jb][1] * 0.125f + kb4.y;
+        sc[jb][2] = sc[jb][2] * 0.125f + kb4.z;
+        sc[jb][3] = sc[jb][3] * 0.125f + kb4.w;
+        mx = fmaxf(mx, fmaxf(fmaxf(sc[jb][0], sc[jb][1]), fmaxf(sc[jb][2], sc[jb][3])));
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mu = mx == -INFINITY ? 0.f : mx;
+    float sum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < SA_NKB; ++jb)
+      if (jb < nkb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(sc[jb][r] - mu);
+          sc[jb][r] = pv;
+          sum += pv;
+        }
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+
+    // ---- O = P . V with the key permutation described above
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int tq = fr >> 2, tp = fr & 3;                       // transposed read: this lane addresses block row tq, columns 4 tp .. +3
+#pragma unroll
+    for (int ks = 0; ks < SA_NKB / 2; ++ks) {
+      if (ks < nks) {
+        // A fragment: own probabilities of key blocks 2 ks and 2 ks + 1 (block 2 ks + 1 may lie beyond nkb: zeros)
+        uint32_t ph[4], pl[4];
+        const f32x4 p0 = sc[2 * ks], p1 = sc[2 * ks + 1];       // sc[jb >= nkb] is 0
+        if (X3) {
+          split_bf16x2(p0[0] * inv, p0[1] * inv, ph[0], pl[0]);
+          split_bf16x2(p0[2] * inv, p0[3] * inv, ph[1], pl[1]);
+          split_bf16x2(p1[0] * inv, p1[1] * inv, ph[2], pl[2]);
+          split_bf16x2(p1[2] * inv, p1[3] * inv, ph[3], pl[3]);
+        } else {
+          ph[0] = pack_bf16x2(p0[0] * inv, p0[1] * inv);
+          ph[1] = pack_bf16x2(p0[2] * inv, p0[3] * inv);
+          ph[2] = pack_bf16x2(p1[0] * inv, p1[1] * inv);
+          ph[3] = pack_bf16x2(p1[2] * inv, p1[3] * inv);
+        }
+        const bf16x8 pah = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+        bf16x8 pal;
+        if (X3) pal = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+        const int r0 = ks * 32 + fq * 4 + tq, r1 = r0 + 16;    // V rows (keys) this lane addresses in the two blocks
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int dc = db * 2 + (tp >> 1), hb = (tp & 1) * 8;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Vs + sa_off<X3>(r0, sa_chunk<X3>(0, dc)) + hb));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Vs + sa_off<X3>(r1, sa_chunk<X3>(0, dc)) + hb));
+          const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          if (X3) {
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Vs + sa_off<X3>(r0, sa_chunk<X3>(1, dc)) + hb));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Vs + sa_off<X3>(r1, sa_chunk<X3>(1, dc)) + hb));
+            const bf16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pal, vh, o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pah, vl, o[db], 0, 0, 0);
+          }
+          o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pah, vh, o[db], 0, 0, 0);
+        }
+      }
+    }
+    // ---- output block [16 q][64 d] -> per-wave LDS tile in the global chunk order -> whole-row stores
+    // (o[db][r]: row q = fq*4 + r, column d = db*16 + fr)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = fq * 4 + r, d = db * 16 + fr;
+        bf16_t h, lo_;
+        split_bf16(o[db][r], h, lo_);
+        *(bf16_t*)(Os + row * RB + sa_chunk<X3>(0, d >> 3) * 16 + (d & 7) * 2) = h;
+        if (X3) *(bf16_t*)(Os + row * RB + sa_chunk<X3>(1, d >> 3) * 16 + (d & 7) * 2) = lo_;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 16 * CH / 64; ++it) {
+      const int idx = lane + 64 * it, row = idx / CH, c = idx % CH;
+      const int q = qb * 16 + row;
+      if (q < S) {
+        const uint4 v = *(const uint4*)(Os + row * RB + c * 16);
+        const long long base = ((long long)b * S + q) * H + head * HD;
+        if (X3) {
+          if (il_out) {
+            *(uint4*)(P.ctx_hi + ser_il_off(base) + c * 8) = v;
+          } else {      // planar output planes: chunk c = (dc >> 2) * 8 + plane * 4 + (dc & 3)
+            const int plane = (c >> 2) & 1, dc = ((c >> 3) << 2) + (c & 3);
+            *(uint4*)((plane ? P.ctx_lo : P.ctx_hi) + base + dc * 8) = v;
+          }
+        } else {
+          *(uint4*)(P.ctx_hi + base + c * 8) = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();      // the tile is reused by this wave's next query block
+  }
+}
+
+// one or two problems (same clip count and head count) in one launch; the (clip, head) blocks of problem 0 come first
+template <bool X3>
+__global__ __launch_bounds__(SA_WAVES * 64) void self_attention_small_kernel(const AttnProb P0, const AttnProb P1, const int n0,
+                                                                               const int heads) {
+  __shared__ __attribute__((aligned(1024))) char lds[SaCfg<X3>::LDS_BYTES];
+  const int blk = blockIdx.x;
+  if (blk < n0) attn_small_body<X3>(P0, blk % heads, blk / heads, lds);
+  else attn_small_body<X3>(P1, (blk - n0) % heads, (blk - n0) / heads, lds);
+}
+
+// the resident-K/V kernel takes one-plane problems and three-product problems whose INPUT planes are interleaved
+static bool small_ok(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* ctx_lo, int S) {
+  if (S > SA_MAXKEYS) return false;
+  const bool x3 = qkv_lo && ctx_lo;
+  return !x3 || ser_is_il(qkv_hi, qkv_lo);
+}
+static int g_attn_force_generic = 0;      // tests: run the chunked kernel on shapes the resident kernel would take
+extern "C" int ser_debug_set_attention_generic(int on) { g_attn_force_generic = on; return 0; }
 
 template <bool X3>
 __global__ __launch_bounds__(256) void self_attention_kernel(const AttnProb P) {
@@ -211,6 +454,15 @@ int ser_launch_self_attention_pair(const SerAttnArgs& a, const SerAttnArgs& b, h
     return ser_launch_self_attention(b.qkv_hi, b.qkv_lo, b.key_mask, b.B, b.S, b.heads, b.ctx_hi, b.ctx_lo, st);
   }
   SER_REQUIRE(a.B > 0 && a.S > 0 && b.S > 0 && a.heads > 0, "self_attention: empty problem");
+  if (!g_attn_force_generic && small_ok(a.qkv_hi, a.qkv_lo, a.ctx_lo, a.S) && small_ok(b.qkv_hi, b.qkv_lo, b.ctx_lo, b.S)) {
+    const int Hh = a.heads * HD, n0 = a.B * a.heads;
+    const AttnProb Q0{a.qkv_hi, x3 ? a.qkv_lo : nullptr, a.key_mask, a.S, Hh, a.ctx_hi, x3 ? a.ctx_lo : nullptr};
+    const AttnProb Q1{b.qkv_hi, x3 ? b.qkv_lo : nullptr, b.key_mask, b.S, Hh, b.ctx_hi, x3 ? b.ctx_lo : nullptr};
+    if (x3) hipLaunchKernelGGL(self_attention_small_kernel<true>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
+    else hipLaunchKernelGGL(self_attention_small_kernel<false>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
   const int H = a.heads * HD, qt0 = ceil_div(a.S, 64);
   const AttnProb P0{a.qkv_hi, x3 ? a.qkv_lo : nullptr, a.key_mask, a.S, H, a.ctx_hi, x3 ? a.ctx_lo : nullptr};
   const AttnProb P1{b.qkv_hi, x3 ? b.qkv_lo : nullptr, b.key_mask, b.S, H, b.ctx_hi, x3 ? b.ctx_lo : nullptr};
@@ -226,6 +478,14 @@ int ser_launch_self_attention(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const 
   SER_REQUIRE(B > 0 && S > 0 && heads > 0, "self_attention: empty problem");
   SER_REQUIRE(qkv_hi && ctx_hi, "self_attention: null planes");
   const int H = heads * HD;
+  if (!g_attn_force_generic && small_ok(qkv_hi, qkv_lo, ctx_lo, S)) {
+    const bool x3 = qkv_lo && ctx_lo;
+    const AttnProb Q{qkv_hi, x3 ? qkv_lo : nullptr, key_mask, S, H, ctx_hi, x3 ? ctx_lo : nullptr};
+    if (x3) hipLaunchKernelGGL(self_attention_small_kernel<true>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
+    else hipLaunchKernelGGL(self_attention_small_kernel<false>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
+    SER_LAUNCH_CHECK();
+    return SER_OK;
+  }
   dim3 grid(ceil_div(S, 64), heads, B), block(256);
   if (qkv_lo && ctx_lo) {
     const AttnProb P{qkv_hi, qkv_lo, key_mask, S, H, ctx_hi, ctx_lo};

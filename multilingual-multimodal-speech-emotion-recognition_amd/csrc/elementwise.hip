@@ -35,20 +35,23 @@ __global__ void split_kernel(const float* __restrict__ x, bf16_t* __restrict__ h
                              long long n) {
   long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  const bool il = ser_is_il(hi, lo);       // interleaved planes (lo == hi + 32): offsets map by ser_il_off
   for (; i < n; i += stride) {
     if (i + 3 < n) {
       const float4 v = *(const float4*)(x + i);
       bf16_t h[4], l[4];
       split_bf16(v.x, h[0], l[0]); split_bf16(v.y, h[1], l[1]);
       split_bf16(v.z, h[2], l[2]); split_bf16(v.w, h[3], l[3]);
-      *(uint2*)(hi + i) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-      if (lo) *(uint2*)(lo + i) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+      const long long o = il ? ser_il_off(i) : i;
+      *(uint2*)(hi + o) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+      if (lo) *(uint2*)(lo + o) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
     } else {
       for (long long k = i; k < n; ++k) {
         bf16_t h, l;
         split_bf16(x[k], h, l);
-        hi[k] = h;
-        if (lo) lo[k] = l;
+        const long long o = il ? ser_il_off(k) : k;
+        hi[o] = h;
+        if (lo) lo[o] = l;
       }
     }
   }
@@ -58,6 +61,7 @@ int ser_launch_split(const float* x, bf16_t* hi, bf16_t* lo, long long n, hipStr
   if (n <= 0) return SER_OK;
   SER_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)hi % 8 == 0) && (!lo || (uintptr_t)lo % 8 == 0),
               "split_bf16: pointers must be 16/8-byte aligned");
+  SER_REQUIRE(!ser_is_il(hi, lo) || n % SER_IL_GROUP == 0, "split_bf16: the interleaved layout needs n %% %d == 0", SER_IL_GROUP);
   long long blocks = (n / 4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
@@ -138,8 +142,9 @@ SER_DEVFN void ln_row(const LnProb& P, const int row, const int lane) {
         bf16_t h[4], l[4];
         split_bf16(o.x, h[0], l[0]); split_bf16(o.y, h[1], l[1]);
         split_bf16(o.z, h[2], l[2]); split_bf16(o.w, h[3], l[3]);
-        *(uint2*)(yhi + off) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-        if (ylo) *(uint2*)(ylo + off) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+        const long long op = ser_is_il(yhi, ylo) ? ser_il_off(off) : off;
+        *(uint2*)(yhi + op) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+        if (ylo) *(uint2*)(ylo + op) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
       }
     }
   }
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(256) void layernorm_pair_kernel(const LnProb P0, co
 int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows,
                          int D, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
   SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d unsupported (need D %% 4 == 0, D <= 1024)", D);
+  SER_REQUIRE(!ser_is_il(yhi, ylo) || D % SER_IL_GROUP == 0, "layernorm: interleaved output planes need D %% %d == 0", SER_IL_GROUP);
   if (rows <= 0) return SER_OK;
   dim3 grid(ceil_div(rows, 4)), block(256);
   const int nv = ceil_div(D / 4, 64);
@@ -183,6 +189,7 @@ int ser_launch_layernorm_pair(const SerLnArgs& a, const SerLnArgs& b, hipStream_
     return ser_launch_layernorm(b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo, st);
   }
   SER_REQUIRE(a.D % 4 == 0 && a.D >= 4 && a.D <= 1024, "layernorm: D=%d unsupported", a.D);
+  SER_REQUIRE(!(ser_is_il(a.yhi, a.ylo) || ser_is_il(b.yhi, b.ylo)) || a.D % SER_IL_GROUP == 0, "layernorm: interleaved output planes need D %% %d == 0", SER_IL_GROUP);
   const LnProb P0{a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo};
   const LnProb P1{b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo};
   dim3 grid(ceil_div(a.rows + b.rows, 4)), block(256);
@@ -305,7 +312,8 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* __restrict__ wa
         bf16_t h0, l0, h1, l1;
         split_bf16(v0, h0, l0);
         split_bf16(v1, h1, l1);
-        const long long o = ((long long)b * L0 + t0 + t) * C0 + c;
+        long long o = ((long long)b * L0 + t0 + t) * C0 + c;
+        if (ser_is_il(yhi, ylo)) o = ser_il_off(o);
         *(uint32_t*)(yhi + o) = h0 | ((uint32_t)h1 << 16);
         if (ylo) *(uint32_t*)(ylo + o) = l0 | ((uint32_t)l1 << 16);
       }
@@ -441,9 +449,12 @@ __global__ __launch_bounds__(256) void conv0_apply_kernel(const float* __restric
     const float2 st0 = cstats[(long long)b * C0 + c], st1 = cstats[(long long)b * C0 + c + 1];
     const ser_v2f g = {gn_g[c] * st0.y, gn_g[c + 1] * st1.y};
     const ser_v2f o = {gn_b[c] - st0.x * g.x, gn_b[c + 1] - st1.x * g.y};
-    uint32_t* ph = (uint32_t*)(yhi + ((long long)b * L0 + t0) * C0 + c);
-    uint32_t* pl = LO ? (uint32_t*)(ylo + ((long long)b * L0 + t0) * C0 + c) : nullptr;
-    const int rowu = C0 / 2;
+    // interleaved planes: a frame row is 2 * C0 bf16, channel c sits at ser_il_off(c), lo 32 elements further
+    const bool il = LO && ser_is_il(yhi, ylo);
+    const long long e0 = il ? ((long long)b * L0 + t0) * C0 * 2 + ser_il_off(c) : ((long long)b * L0 + t0) * C0 + c;
+    uint32_t* ph = (uint32_t*)(yhi + e0);
+    uint32_t* pl = LO ? (uint32_t*)(ylo + e0) : nullptr;
+    const int rowu = il ? C0 : C0 / 2;
 #pragma unroll 4
     for (int t = 0; t < nt; ++t) {
       ser_v2f acc = {0.f, 0.f};
@@ -478,6 +489,7 @@ int ser_launch_conv0(const float* wave, int B, int T, const float* w, const floa
                      int KW, int ST, int L0, bf16_t* yhi, bf16_t* ylo, void* scratch, hipStream_t st) {
   SER_REQUIRE(KW <= C0_MAXK && ST <= 8 && C0 % 2 == 0, "conv0: unsupported kernel=%d stride=%d channels=%d", KW, ST, C0);
   SER_REQUIRE(L0 == (T - KW) / ST + 1 && L0 > 0, "conv0: bad output length");
+  SER_REQUIRE(!ser_is_il(yhi, ylo) || C0 % SER_IL_GROUP == 0, "conv0: interleaved output planes need C0 %% %d == 0", SER_IL_GROUP);
   const int chunks = ceil_div(L0, C0_FT);
   char* p = (char*)scratch;
   float2* wstats = (float2*)p; p += (((size_t)B * sizeof(float2)) + 255) & ~(size_t)255;
@@ -616,8 +628,9 @@ __global__ __launch_bounds__(256) void xlmr_embed_kernel(const int64_t* __restri
       bf16_t h[4], l[4];
       split_bf16(o.x, h[0], l[0]); split_bf16(o.y, h[1], l[1]);
       split_bf16(o.z, h[2], l[2]); split_bf16(o.w, h[3], l[3]);
-      if (yhi) *(uint2*)(yhi + off) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
-      if (ylo) *(uint2*)(ylo + off) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+      const long long op = ser_is_il(yhi, ylo) ? ser_il_off(off) : off;
+      if (yhi) *(uint2*)(yhi + op) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+      if (ylo) *(uint2*)(ylo + op) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
     }
   }
 }
@@ -626,6 +639,7 @@ int ser_launch_xlmr_embed(const int64_t* ids, int B, int S, const float* wemb, c
                           const float* gamma, const float* beta, float eps, int D, int vocab, int max_pos, int pad_id,
                           int* pos_scratch, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st) {
   SER_REQUIRE(D % 4 == 0 && D <= 1024, "xlmr_embed: D=%d unsupported", D);
+  SER_REQUIRE(!ser_is_il(yhi, ylo) || D % SER_IL_GROUP == 0, "xlmr_embed: interleaved output planes need D %% %d == 0", SER_IL_GROUP);
   hipLaunchKernelGGL(xlmr_posid_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, st, ids, B, S, pad_id, max_pos, pos_scratch);
   const int rows = B * S;
   dim3 grid(ceil_div(rows, 4)), block(256);

@@ -10,8 +10,16 @@ struct Planes {
   bf16_t* lo;
 };
 
-static Planes take_planes(SerArena& ar, size_t n, bool x3) {
+// split-plane activation buffer of n elements.  Three-product mode: ONE array of 2 n elements with the planes
+// interleaved in groups of 32 (ser_common.h; marked by lo == hi + 32) — what every GEMM / LayerNorm / attention kernel of
+// the encoders reads and writes; `planar` keeps two separate planes (the positional conv's Toeplitz slab).
+static Planes take_planes(SerArena& ar, size_t n, bool x3, bool planar = false) {
   Planes p;
+  if (x3 && !planar) {
+    p.hi = ar.get<bf16_t>(2 * n);
+    p.lo = p.hi ? p.hi + SER_IL_GROUP : nullptr;
+    return p;
+  }
   p.hi = ar.get<bf16_t>(n);
   p.lo = x3 ? ar.get<bf16_t>(n) : nullptr;
   return p;
@@ -177,6 +185,8 @@ static int check_w2v_cfg(const SerW2vConfig* c) {
     SER_REQUIRE((c->conv_kernel[i] * c->conv_dim[i - 1]) % 64 == 0 && c->conv_dim[i - 1] % 8 == 0,
                 "wav2vec2: conv layer %d K must be a multiple of 64", i);
   SER_REQUIRE(c->conv_dim[c->n_conv - 1] % 4 == 0 && c->conv_dim[c->n_conv - 1] <= 1024, "wav2vec2: conv_dim too large");
+  for (int i = 0; i < c->n_conv; ++i)
+    SER_REQUIRE(c->conv_dim[i] % SER_IL_GROUP == 0, "wav2vec2: conv_dim[%d]=%d must be a multiple of %d", i, c->conv_dim[i], SER_IL_GROUP);
   return SER_OK;
 }
 
@@ -197,7 +207,7 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
   float* feat = ar.get<float>(rows * Cl);
   Planes featn = take_planes(ar, rows * Cl, x3);
   float* z = ar.get<float>(rows * H);
-  Planes slab = take_planes(ar, (size_t)B * G * (S + Kp - 1) * Cg, x3);
+  Planes slab = take_planes(ar, (size_t)B * G * (S + Kp - 1) * Cg, x3, /*planar=*/true);
   float* hsum = ar.get<float>(rows * H);
   float* ha = ar.get<float>(rows * H);
   float* hb = ar.get<float>(rows * H);

@@ -5,7 +5,12 @@
 // Operands are bf16 planes with K contiguous.  In parity mode (both hi and lo planes present)
 // every product is  a_hi*w_hi + a_lo*w_hi + a_hi*w_lo  (three v_mfma_f32_16x16x32_bf16), which
 // carries ~2^-16 relative error per product instead of bf16's 2^-8; in fast mode only the hi
-// planes are read.
+// planes are read.  Three operand modes:
+//   M_BF16  hi planes only, one product, a k-tile = 64 values of k (128 B per row)
+//   M_X3P   planar hi and lo planes (the positional conv's Toeplitz view needs it), both staged: two LDS images per operand
+//   M_X3I   interleaved hi/lo (ser_common.h): a 128-B line = 32 values of k with both planes, so a k-tile stages exactly
+//           the bytes of a bf16 k-tile and feeds 3 MFMAs per accumulator instead of 2 — same LDS footprint, same tile
+//           heights, two workgroups per CU; the summation order equals M_X3P's (bit-identical results).
 //
 // Structure: BMxBN output tile per 256-thread workgroup (4 waves as 2x2; BM = 64...192, BN = 128 or 64), BK = 64.
 // Global -> LDS goes through global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip): one wave
@@ -28,17 +33,6 @@ namespace {
 #ifndef SER_GEMM_DIAG
 #define SER_GEMM_DIAG 0
 #endif
-// Epilogue form.  0 (product): accumulators -> LDS half tile -> 16-byte row-coalesced stores, two passes.
-// 1 (probe builds only): the MFMA operands are swapped (W fragment first), so a lane's four accumulator registers are
-// four CONSECUTIVE columns of one row and go to global memory straight from registers (8-byte bf16 / 16-byte fp32
-// stores, 32 / 64 contiguous bytes per row and instruction), no LDS pass, no workgroup barriers.  Measured
-// (scripts/gemm_phase_probe.py, profiles/r01_m_gemm_phase_probe.txt): the LDS pass + arithmetic shrink from 4.9 to
-// 1.7 us per 192x128 launch but the narrow stores cost 7.9 instead of 3.6 us; -3 % / +5 % stand-alone depending on the
-// shape and +3.5 % on the overlapped step (3.64 vs 3.52 ms) — not the default.
-#ifndef SER_GEMM_EPI_DIRECT
-#define SER_GEMM_EPI_DIRECT 0
-#endif
-
 constexpr int BK = 64;           // bf16 elements per k-tile = 128 B per row
 constexpr int ROW_BYTES = 128;
 
@@ -89,13 +83,15 @@ SER_DEVFN float act_const(float v) {
   return ACT == SER_ACT_GELU ? gelu_erf(v) : ACT == SER_ACT_RELU ? fmaxf(v, 0.0f) : v;
 }
 
-template <int BM, int BN, bool X3, int NS = 2>
+enum { M_BF16 = 0, M_X3P = 1, M_X3I = 2 };
+
+template <int BM, int BN, int MODE, int NS = 2>
 struct GemmCfg {
-  static constexpr int NPL = X3 ? 2 : 1;                    // planes per operand
+  static constexpr int NPL = MODE == M_X3P ? 2 : 1;          // LDS images per operand
   static constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
   static constexpr int STAGE = (A_TILE + W_TILE) * NPL;
   static constexpr int EPI_BYTES = (BM / 2) * (BN + 4) * 4;  // fp32 HALF tile staged for the coalesced epilogue (two passes)
-  static constexpr int LDS_RAW = (SER_GEMM_EPI_DIRECT || NS * STAGE > EPI_BYTES) ? NS * STAGE : EPI_BYTES;
+  static constexpr int LDS_RAW = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
   static constexpr int GLDS = (BM / 32 + BN / 32) * NPL;       // LDS-DMA instructions per stage per wave
   // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
   // GEMMs on another stream, and a small workgroup that cannot get LDS waits for a whole GEMM workgroup to retire
@@ -112,13 +108,16 @@ SER_DEVFN void wait_dma_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, bool X3, int NS = 2>
+template <int BM, int BN, int MODE, int NS = 2>
 SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, char* lds) {
-  constexpr int NPL = GemmCfg<BM, BN, X3, NS>::NPL;
-  constexpr int A_TILE = GemmCfg<BM, BN, X3, NS>::A_TILE, W_TILE = GemmCfg<BM, BN, X3, NS>::W_TILE;
-  constexpr int STAGE = GemmCfg<BM, BN, X3, NS>::STAGE;
-  constexpr int GLDS = GemmCfg<BM, BN, X3, NS>::GLDS;
+  constexpr bool X3 = MODE == M_X3P, IL = MODE == M_X3I;
+  constexpr int NPL = GemmCfg<BM, BN, MODE, NS>::NPL;
+  constexpr int A_TILE = GemmCfg<BM, BN, MODE, NS>::A_TILE, W_TILE = GemmCfg<BM, BN, MODE, NS>::W_TILE;
+  constexpr int STAGE = GemmCfg<BM, BN, MODE, NS>::STAGE;
+  constexpr int GLDS = GemmCfg<BM, BN, MODE, NS>::GLDS;
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int PM = IL ? 2 : 1;                    // physical elements per logical element along K (interleaved: hi + lo)
+  constexpr int KT = IL ? 32 : 64;                  // values of k per k-tile (a k-tile is always 128 B per row)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -144,7 +143,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int b1 = bz / g.nb2, b2 = bz % g.nb2;
 
-  const long long aoff = b1 * g.sa1 + b2 * g.sa2, woff = b1 * g.sw1 + b2 * g.sw2;
+  const long long aoff = (b1 * g.sa1 + b2 * g.sa2) * PM, woff = (b1 * g.sw1 + b2 * g.sw2) * PM;
   const bf16_t* a_hi = g.a_hi + aoff;
   const bf16_t* w_hi = g.w_hi + woff;
   const bf16_t* a_lo = X3 ? g.a_lo + aoff : nullptr;
@@ -156,10 +155,10 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / BK;
+  const int nk = g.K / KT;
   unsigned offa[BM / 32], offw[BN / 32];
-  stage_offsets<BM>(offa, g.lda, m0, g.M - 1, wave, lane);
-  stage_offsets<BN>(offw, g.ldw, n0, g.N - 1, wave, lane);
+  stage_offsets<BM>(offa, (long long)g.lda * PM, m0, g.M - 1, wave, lane);
+  stage_offsets<BN>(offw, (long long)g.ldw * PM, n0, g.N - 1, wave, lane);
   auto stage = [&](int kt, int buf) {
     if (SER_GEMM_DIAG & 4) return;
     char* s = lds + buf * STAGE;
@@ -188,6 +187,43 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     rbuf = rbuf + 1 == NS ? 0 : rbuf + 1;
     const char* sa = s + wm * WM * ROW_BYTES;
     const char* sw = s + A_TILE * NPL + wn * WN * ROW_BYTES;
+    if constexpr (IL) {
+      // interleaved planes: chunks 0-3 of a row are the hi values of this k-tile's 32 k, chunks 4-7 their lo values.
+      // One MFMA k-step per k-tile, three products per accumulator; the A fragments of row block i+1 are requested
+      // before the MFMAs of row block i (pinned), so their LDS latency hides under 3*TN MFMAs.
+      bf16x8 bh[TN], bl[TN], ah[TM], al[TM];
+      constexpr bool RUN = !(SER_GEMM_DIAG & 2);
+      if (RUN) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh[j] = lds_frag(sw, j * 16 + fr, fq);
+          bl[j] = lds_frag(sw, j * 16 + fr, 4 + fq);
+        }
+        ah[0] = lds_frag(sa, fr, fq);
+        al[0] = lds_frag(sa, fr, 4 + fq);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + NS - 1 < nk) stage(kt + NS - 1, wbuf);
+      wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (RUN) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (i + 1 < TM) {
+            ah[i + 1] = lds_frag(sa, (i + 1) * 16 + fr, fq);
+            al[i + 1] = lds_frag(sa, (i + 1) * 16 + fr, 4 + fq);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     // Fragment reads are software-pipelined by hand: the ds_read_b128s of k-step ks+1 are issued after the first MFMA
     // rows of k-step ks and pinned there (sched_barrier: nothing is scheduled across it), so they land under the
     // remaining rows (the summation order per accumulator is unchanged).  Left alone, the compiler keeps one
@@ -218,19 +254,11 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
       for (int i = i_lo; i < i_hi; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if (SER_GEMM_EPI_DIRECT) {        // D^T: rows of the MFMA = columns n, same products in the same order
-            if (X3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cur][j], al[cur][i], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
-          } else {
-            if (X3) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+          if (X3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bl[cur][j], acc[i][j], 0, 0, 0);
           }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cur][i], bh[cur][j], acc[i][j], 0, 0, 0);
         }
     };
     constexpr int HEAD = TM >= 3 ? TM / 3 : 1;     // MFMA rows issued before the next k-step's reads go out
@@ -242,6 +270,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
       if (ks + 1 < KS) read_frags(ks + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       mfma_rows(cur, HEAD, TM);
+    }
     }
   }
 
@@ -259,109 +288,11 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     if (sacc == 123456.789f && g.c_f32) g.c_f32[0] = sacc;
     return;
   }
-  if (SER_GEMM_EPI_DIRECT) {
-    // swapped-operand C/D map: acc[i][j][r] = C[m0 + wm*WM + i*16 + (lane&15)][n0 + wn*WN + j*16 + (lane>>4)*4 + r]
-    const long long coff = b1 * g.sc1 + b2 * g.sc2;
-    const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
-    const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
-    // 4-wide form: four consecutive columns per lane, 8/16-byte accesses; anything ragged or unaligned (never the
-    // case on the path: N, ldc, ldr are multiples of 4) goes element by element
-    const bool al4 = ((g.ldc & 3) == 0) && ((coff & 3) == 0) &&
-                     (!res || (((g.ldr & 3) == 0) && ((((uintptr_t)res) & 15) == 0)));
-    // the residual values of a group of block columns (half the tile; one column for the 160/192-row tiles) are requested
-    // before the first one is used: 2-4 exposed load latencies per tile instead of one per 16x16 block, in at most
-    // 32 registers, so that VGPRs + AGPRs stay <= 256 (two workgroups per CU)
-    constexpr int TNH = TM > 4 ? 1 : (TN >= 2 ? TN / 2 : 1);     // block columns per group
-    constexpr int NG = TN / TNH;
-    float4 rv[TM][TNH];
-    auto prefetch_residual = [&](int jh) {
-      if (!(res && al4)) return;
-#pragma unroll
-      for (int jj = 0; jj < TNH; ++jj)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int n = n0 + wn * WN + (jh * TNH + jj) * 16 + fq * 4, m = m0 + wm * WM + i * 16 + fr;
-          if (m < g.M && n + 3 < g.N) rv[i][jj] = *(const float4*)(res + (long long)m * g.ldr + n);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // one copy of the store code per activation, chosen once (uniform), instead of a switch per element
-    auto epilogue = [&](auto act_tag, auto half_tag) {
-      constexpr int ACT = decltype(act_tag)::value, JH = decltype(half_tag)::value;
-#pragma unroll
-      for (int j = JH * TNH; j < (JH + 1) * TNH; ++j) {
-        const int n = n0 + wn * WN + j * 16 + fq * 4;
-        if (n >= g.N) continue;
-        const bool vec = al4 && (n + 3 < g.N);
-        float bv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = (bias && n + e < g.N) ? bias[n + e] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int m = m0 + wm * WM + i * 16 + fr;
-          if (m >= g.M) continue;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_const<ACT>(acc[i][j][e] + bv[e]);
-          const long long o = coff + (long long)m * g.ldc + n;
-          if (SER_GEMM_DIAG & 8) {
-            if (v[0] + v[1] + v[2] + v[3] == 123456.789f && g.c_hi) g.c_hi[o] = 1;
-            continue;
-          }
-          if (vec) {
-            if (res) {
-              const float4 r0 = rv[i][j - JH * TNH];
-              v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-            }
-            if (g.c_f32) *(float4*)(g.c_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
-            if (g.c_hi) {
-              uint32_t ph[2], pl[2];
-              if (g.c_lo) {
-                split_bf16x2(v[0], v[1], ph[0], pl[0]);
-                split_bf16x2(v[2], v[3], ph[1], pl[1]);
-                *(uint2*)(g.c_lo + o) = make_uint2(pl[0], pl[1]);
-              } else {
-                ph[0] = pack_bf16x2(v[0], v[1]);
-                ph[1] = pack_bf16x2(v[2], v[3]);
-              }
-              *(uint2*)(g.c_hi + o) = make_uint2(ph[0], ph[1]);
-            }
-          } else {
-#pragma unroll 1
-            for (int e = 0; e < 4 && n + e < g.N; ++e) {
-              float x = e == 0 ? v[0] : e == 1 ? v[1] : e == 2 ? v[2] : v[3];
-              if (res) x += res[(long long)m * g.ldr + n + e];
-              if (g.c_f32) g.c_f32[o + e] = x;
-              if (g.c_hi) {
-                bf16_t h, l;
-                split_bf16(x, h, l);
-                g.c_hi[o + e] = h;
-                if (g.c_lo) g.c_lo[o + e] = l;
-              }
-            }
-          }
-        }
-      }
-    };
-    auto half = [&](auto half_tag) {
-      prefetch_residual(decltype(half_tag)::value);
-      if (g.act == SER_ACT_GELU) epilogue(std::integral_constant<int, SER_ACT_GELU>{}, half_tag);
-      else if (g.act == SER_ACT_RELU) epilogue(std::integral_constant<int, SER_ACT_RELU>{}, half_tag);
-      else epilogue(std::integral_constant<int, SER_ACT_NONE>{}, half_tag);
-    };
-    static_assert(NG == 1 || NG == 2 || NG == 4, "epilogue groups");
-    half(std::integral_constant<int, 0>{});
-    if constexpr (NG > 1) half(std::integral_constant<int, 1>{});
-    if constexpr (NG > 2) {
-      half(std::integral_constant<int, 2>{});
-      half(std::integral_constant<int, 3>{});
-    }
-    return;
-  }
 
   const long long coff = b1 * g.sc1 + b2 * g.sc2;
   const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
   const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
+  const bool c_il = ser_is_il(g.c_hi, g.c_lo);      // interleaved output planes: one array, offsets mapped by ser_il_off
   constexpr int TPR = BN / 8;                        // threads per row, 8 columns each
   constexpr int RPI = 256 / TPR;                     // rows per iteration
   const int tc = (tid % TPR) * 8, tr = tid / TPR;
@@ -392,6 +323,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], g.act);
     const long long o = coff + (long long)m * g.ldc + n;
+    const long long op = c_il ? ser_il_off(o) : o;   // plane offset (8 consecutive columns never straddle a 32-group)
     if (SER_GEMM_DIAG & 8) {
       if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 123456.789f && g.c_hi) g.c_hi[o] = 1;
       continue;
@@ -416,12 +348,12 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
         if (g.c_lo) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) split_bf16x2(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
-          *(uint4*)(g.c_lo + o) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          *(uint4*)(g.c_lo + op) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) ph[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
         }
-        *(uint4*)(g.c_hi + o) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        *(uint4*)(g.c_hi + op) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
       }
     } else {
 #pragma unroll
@@ -433,8 +365,9 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
         if (g.c_hi) {
           bf16_t h, l;
           split_bf16(x, h, l);
-          g.c_hi[o + e] = h;
-          if (g.c_lo) g.c_lo[o + e] = l;
+          const long long oe = c_il ? ser_il_off(o + e) : o + e;
+          g.c_hi[oe] = h;
+          if (g.c_lo) g.c_lo[oe] = l;
         }
       }
     }
@@ -446,11 +379,11 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 // workgroup walks tiles `blockIdx.x, blockIdx.x + gridDim.x, ...` of the flattened (batch entry, tile) space.  No tile
 // ever waits in the dispatcher's queue, so the small head kernels of the other stream are placed as soon as they
 // arrive instead of behind this kernel's not-yet-dispatched workgroups.
-template <int BM, int BN, bool X3, int NS = 2>
-__global__ __launch_bounds__(256, (GemmCfg<BM, BN, X3, NS>::WG_PER_CU)) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
-  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3, NS>::LDS_BYTES];
+template <int BM, int BN, int MODE, int NS = 2>
+__global__ __launch_bounds__(256, (GemmCfg<BM, BN, MODE, NS>::WG_PER_CU)) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS>::LDS_BYTES];
   for (int w = blockIdx.x; w < total; w += gridDim.x) {
-    gemm_tile<BM, BN, X3, NS>(g, w % tiles, w / tiles, lds);
+    gemm_tile<BM, BN, MODE, NS>(g, w % tiles, w / tiles, lds);
     __syncthreads();     // the epilogue's LDS tile is dead before the next tile's first stage lands
   }
 }
@@ -458,15 +391,15 @@ __global__ __launch_bounds__(256, (GemmCfg<BM, BN, X3, NS>::WG_PER_CU)) void gem
 // Two independent problems in one launch (the layer-l GEMMs of Wav2Vec2 and of XLM-R have no dependence on each
 // other): the tiles of the small problem come first in the grid, so they start at once and ride along with the
 // large one instead of queueing, launch after launch, on a second stream behind it.
-template <int BM, int BN, bool X3, int NS = 2>
-__global__ __launch_bounds__(256, (GemmCfg<BM, BN, X3, NS>::WG_PER_CU)) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
+template <int BM, int BN, int MODE, int NS = 2>
+__global__ __launch_bounds__(256, (GemmCfg<BM, BN, MODE, NS>::WG_PER_CU)) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
                                                              const int tiles0, const int tiles1) {
-  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, X3, NS>::LDS_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS>::LDS_BYTES];
   // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches
   const bool first = (int)blockIdx.x < total0;
   const SerGemmArgs* g = first ? &g0 : &g1;
   const int w = first ? blockIdx.x : blockIdx.x - total0, tiles = first ? tiles0 : tiles1;
-  gemm_tile<BM, BN, X3, NS>(*g, w % tiles, w / tiles, lds);
+  gemm_tile<BM, BN, MODE, NS>(*g, w % tiles, w / tiles, lds);
 }
 
 // ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
@@ -502,12 +435,35 @@ static int stages_for() {
   return v < 2 ? 2 : (v > 4 ? 4 : v);
 }
 
+// operand mode of a problem (host side): no lo planes = one product; lo == hi + 32 elements on BOTH operands =
+// interleaved three-product; otherwise planar three-product
+static int gemm_mode(const SerGemmArgs& g) {
+  if (!g.a_lo || !g.w_lo) return M_BF16;
+  return (ser_is_il(g.a_hi, g.a_lo) && ser_is_il(g.w_hi, g.w_lo)) ? M_X3I : M_X3P;
+}
+
+template <int BM, int BN, int MODE>
+static void launch_nt_mode(const SerGemmArgs& g, dim3 grid, int tiles, int total, hipStream_t st) {
+  dim3 block(256);
+  if constexpr (MODE == M_X3P) {
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+  } else {
+    const int ns = stages_for<BM, BN>();
+    if (ns == 3)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE, 3>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    else if (ns == 4 && BM * BN <= 64 * 128)
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    else
+      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+  }
+}
+
 template <int BM, int BN>
 int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
   const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
   const int total = tiles * g.nb1 * g.nb2;
   const int cap = g_gemm_persist_cap > 0 ? g_gemm_persist_cap : total;
-  dim3 grid(total < cap ? total : cap), block(256);
+  dim3 grid(total < cap ? total : cap);
   ProfRec rec;
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventCreate(&rec.e0));
@@ -515,19 +471,15 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
     rec.flops = 2.0 * g.M * (double)g.N * g.K * g.nb1 * g.nb2;   // algorithmic (one product per MAC)
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
-  if (g.a_lo && g.w_lo) {
-    constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;     // parity mode keeps the two classic heights
-    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the 3-product mode", BM);
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<XBM, BN, true>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+  const int mode = gemm_mode(g);
+  if (mode == M_X3P) {
+    constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;     // the planar form (two LDS images per operand) keeps the two classic heights
+    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the planar 3-product mode", BM);
+    launch_nt_mode<XBM, BN, M_X3P>(g, grid, tiles, total, st);
+  } else if (mode == M_X3I) {
+    launch_nt_mode<BM, BN, M_X3I>(g, grid, tiles, total, st);
   } else {
-    const int ns = stages_for<BM, BN>();
-    constexpr bool MULTI = true;                       // every tile shape is built with two and three LDS buffers
-    if (MULTI && ns == 3)
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (MULTI ? 3 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
-    else if (MULTI && ns == 4 && BM * BN <= 64 * 128)
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false, (MULTI && BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
-    else
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    launch_nt_mode<BM, BN, M_BF16>(g, grid, tiles, total, st);
   }
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventRecord(rec.e1, st));
@@ -537,11 +489,28 @@ int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
   return SER_OK;
 }
 
+template <int BM, int BN, int MODE>
+static void launch_pair_mode(const SerGemmArgs& small, const SerGemmArgs& big, dim3 grid, int total0, int tiles0, int tiles1,
+                             hipStream_t st) {
+  dim3 block(256);
+  if constexpr (MODE == M_X3P) {
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+  } else {
+    const int ns = stages_for<BM, BN>();
+    if (ns == 3)
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, 3>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    else if (ns == 4 && BM * BN <= 64 * 128)
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    else
+      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+  }
+}
+
 template <int BM, int BN>
 int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) {
   const int tiles0 = ceil_div(small.M, BM) * ceil_div(small.N, BN), tiles1 = ceil_div(big.M, BM) * ceil_div(big.N, BN);
   const int total0 = tiles0 * small.nb1 * small.nb2, total1 = tiles1 * big.nb1 * big.nb2;
-  dim3 grid(total0 + total1), block(256);
+  dim3 grid(total0 + total1);
   ProfRec rec;
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventCreate(&rec.e0));
@@ -550,19 +519,15 @@ int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_
                 2.0 * big.M * (double)big.N * big.K * big.nb1 * big.nb2;
     SER_CHECK_HIP(hipEventRecord(rec.e0, st));
   }
-  if (big.a_lo && big.w_lo) {
+  const int mode = gemm_mode(big);
+  if (mode == M_X3P) {
     constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;
-    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the 3-product mode", BM);
-    hipLaunchKernelGGL((gemm_bf16_pair_kernel<XBM, BN, true>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the planar 3-product mode", BM);
+    launch_pair_mode<XBM, BN, M_X3P>(small, big, grid, total0, tiles0, tiles1, st);
+  } else if (mode == M_X3I) {
+    launch_pair_mode<BM, BN, M_X3I>(small, big, grid, total0, tiles0, tiles1, st);
   } else {
-    const int ns = stages_for<BM, BN>();
-    constexpr bool MULTI = true;
-    if (MULTI && ns == 3)
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (MULTI ? 3 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-    else if (MULTI && ns == 4 && BM * BN <= 64 * 128)
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false, (MULTI && BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-    else
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, false>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
+    launch_pair_mode<BM, BN, M_BF16>(small, big, grid, total0, tiles0, tiles1, st);
   }
   if (g_prof_on) {
     SER_CHECK_HIP(hipEventRecord(rec.e1, st));
@@ -574,16 +539,26 @@ int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_
 
 static int gemm_check(const SerGemmArgs& g) {
   SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_bf16: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
-  SER_REQUIRE(g.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", g.K, BK);
-  SER_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm_bf16: lda=%d ldw=%d must be multiples of 8", g.lda, g.ldw);
   SER_REQUIRE(g.a_hi && g.w_hi, "gemm_bf16: null operand");
   SER_REQUIRE(g.nb1 >= 1 && g.nb2 >= 1, "gemm_bf16: bad batch");
+  if (g.a_lo && g.w_lo) SER_REQUIRE(ser_is_il(g.a_hi, g.a_lo) == ser_is_il(g.w_hi, g.w_lo), "gemm_bf16: A and W must use the same plane layout (planar or interleaved)");
+  if (gemm_mode(g) == M_X3I) {
+    const int G = SER_IL_GROUP;
+    SER_REQUIRE(g.K % G == 0 && g.lda % G == 0 && g.ldw % G == 0, "gemm_bf16 (interleaved): K=%d lda=%d ldw=%d must be multiples of %d", g.K, g.lda, g.ldw, G);
+    SER_REQUIRE(g.sa1 % G == 0 && g.sa2 % G == 0 && g.sw1 % G == 0 && g.sw2 % G == 0, "gemm_bf16 (interleaved): batch strides must be multiples of %d", G);
+  } else {
+    SER_REQUIRE(g.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", g.K, BK);
+    SER_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm_bf16: lda=%d ldw=%d must be multiples of 8", g.lda, g.ldw);
+  }
+  if (g.c_hi && ser_is_il(g.c_hi, g.c_lo))
+    SER_REQUIRE(g.ldc % SER_IL_GROUP == 0 && g.sc1 % SER_IL_GROUP == 0 && g.sc2 % SER_IL_GROUP == 0, "gemm_bf16: interleaved output needs ldc=%d and batch strides in multiples of %d", g.ldc, SER_IL_GROUP);
   return SER_OK;
 }
 
 }  // namespace
 
-// Tile choice for BN = 128 in bf16 mode.  At these sizes (a few hundred tiles on 256 CUs) the time of a GEMM is
+// Tile choice for BN = 128 (one-product and interleaved three-product modes share LDS footprint and tile set).  At these
+// sizes (a few hundred tiles on 256 CUs) the time of a GEMM is
 // rounds x (time of one tile), rounds = ceil(tiles / resident workgroups): 522 tiles of 128 rows need two rounds of
 // 512 slots, 432 tiles of 160 rows need one.  Candidates: 64, 96, 128, 160, 192 rows; the cost of a tile grows with
 // its rows plus a constant (W panel, prologue, epilogue).  g_gemm_force_bm overrides (experiments / tests).
@@ -592,24 +567,26 @@ extern "C" int ser_debug_set_gemm_bm(int bm) { g_gemm_force_bm = bm; return 0; }
 
 template <int BM>
 static int slots_per_cu() {
-  const int lds = GemmCfg<BM, 128, false, (BM == 64 ? 3 : 2)>::LDS_BYTES;
+  const int lds = GemmCfg<BM, 128, M_BF16, (BM == 64 ? 3 : 2)>::LDS_BYTES;
   const int by_lds = (160 * 1024) / lds;
   return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
 }
 // measured choices (ser_gemm_tile_hint, filled by the engines' one-time tuning pass) take precedence over the model
-struct TileHint { long long rows; int N, K, bm; };
+struct TileHint { long long rows; int N, K, mode, bm; };
 static std::vector<TileHint> g_tile_hints;
-extern "C" int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm) {
+extern "C" int ser_gemm_tile_hint_mode(long long rows_total, int N, int K, int three_products, int bm) {
+  const int mode = three_products ? M_X3I : M_BF16;
   for (auto& h : g_tile_hints)
-    if (h.rows == rows_total && h.N == N && h.K == K) { h.bm = bm; return SER_OK; }
-  g_tile_hints.push_back(TileHint{rows_total, N, K, bm});
+    if (h.rows == rows_total && h.N == N && h.K == K && h.mode == mode) { h.bm = bm; return SER_OK; }
+  g_tile_hints.push_back(TileHint{rows_total, N, K, mode, bm});
   return SER_OK;
 }
+extern "C" int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm) { return ser_gemm_tile_hint_mode(rows_total, N, K, 0, bm); }
 
-static int pick_bm(long long rows_a, long long rows_b, int N, int K, long long nb_b) {
+static int pick_bm(long long rows_a, long long rows_b, int N, int K, long long nb_b, int mode) {
   if (g_gemm_force_bm) return g_gemm_force_bm;
   for (const auto& h : g_tile_hints)
-    if (h.rows == rows_a + rows_b * nb_b && h.N == N && h.K == K && h.bm) return h.bm;
+    if (h.rows == rows_a + rows_b * nb_b && h.N == N && h.K == K && h.mode == mode && h.bm) return h.bm;
   const int cands[5] = {64, 96, 128, 160, 192};
   const int slots[5] = {slots_per_cu<64>(), slots_per_cu<96>(), slots_per_cu<128>(), slots_per_cu<160>(), slots_per_cu<192>()};
   int best = 128;
@@ -635,7 +612,7 @@ static int launch_bm(const SerGemmArgs* small, const SerGemmArgs& big, hipStream
 }
 static int launch_bn128(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
   const long long rows_a = small ? (long long)small->M * small->nb1 * small->nb2 : 0;
-  switch (pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2)) {
+  switch (pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2, gemm_mode(big))) {
     case 64: return launch_bm<64>(small, big, st);
     case 96: return launch_bm<96>(small, big, st);
     case 160: return launch_bm<160>(small, big, st);
@@ -648,15 +625,15 @@ static int launch_bn128(const SerGemmArgs* small, const SerGemmArgs& big, hipStr
 int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) {
   SER_TRY(gemm_check(small));
   SER_TRY(gemm_check(big));
-  SER_REQUIRE((small.a_lo && small.w_lo) == (big.a_lo && big.w_lo), "gemm_bf16 pair: mixed precision modes");
+  SER_REQUIRE(gemm_mode(small) == gemm_mode(big), "gemm_bf16 pair: mixed precision modes");
   const long long nb = (long long)big.nb1 * big.nb2;
   const long long t128 = (long long)ceil_div(big.M, 128) * ceil_div(big.N, 128) * nb;
   if (big.N <= 64 || small.N <= 64) {          // keep the narrow-N shape out of the pair path
     SER_TRY(ser_launch_gemm_bf16(small, st));
     return ser_launch_gemm_bf16(big, st);
   }
-  const bool x3 = big.a_lo && big.w_lo;
-  if (!x3 && big.M > 64 && big.N >= 128) return launch_bn128(&small, big, st);
+  const bool planar = gemm_mode(big) == M_X3P;
+  if (!planar && big.M > 64 && big.N >= 128) return launch_bn128(&small, big, st);
   if (t128 >= 384 && big.M > 64) return launch_pair_cfg<128, 128>(small, big, st);
   const long long t64 = (long long)ceil_div(big.M, 64) * ceil_div(big.N, 128) * nb;
   if (t64 >= 256 || big.M <= 64) return launch_pair_cfg<64, 128>(small, big, st);
@@ -669,8 +646,8 @@ int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st) {
   const long long nb = (long long)g.nb1 * g.nb2;
   const long long t128 = (long long)ceil_div(g.M, 128) * ceil_div(g.N, 128) * nb;
   if (g.N <= 64) return launch_cfg<128, 64>(g, st);
-  const bool x3 = g.a_lo && g.w_lo;
-  if (!x3 && g.M > 64 && g.N >= 128 && t128 * 4 >= 256) return launch_bn128(nullptr, g, st);
+  const bool planar = gemm_mode(g) == M_X3P;
+  if (!planar && g.M > 64 && g.N >= 128 && t128 * 4 >= 256) return launch_bn128(nullptr, g, st);
   if (t128 >= 384 || g.M <= 64) {
     if (g.M <= 64) return launch_cfg<64, 128>(g, st);
     return launch_cfg<128, 128>(g, st);
@@ -705,6 +682,20 @@ extern "C" int ser_debug_gemm_pair(const uint16_t* a0, const uint16_t* w0, int M
   g[1].a_hi = a1; g[1].w_hi = w1; g[1].M = M1; g[1].N = N1; g[1].K = K1; g[1].lda = K1; g[1].ldw = K1;
   g[1].nb1 = g[1].nb2 = 1; g[1].c_f32 = c1; g[1].ldc = N1;
   return ser_launch_gemm_bf16_pair(g[0], g[1], (hipStream_t)stream);
+}
+
+// debug / probe entry: batched NT GEMM with explicit batch strides (in logical elements; 0 = every batch entry reads the
+// same operand, i.e. an L2-resident working set of any tile count), interleaved three-product planes when il != 0
+extern "C" int ser_debug_gemm_batched(const uint16_t* a, const uint16_t* w, int M, int N, int K, int nb, long long sa,
+                                      long long sw, uint16_t* c, long long sc, int il, void* stream) {
+  SerGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = a; g.w_hi = w;
+  if (il) { g.a_lo = a + SER_IL_GROUP; g.w_lo = w + SER_IL_GROUP; }
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
+  g.nb1 = nb; g.nb2 = 1; g.sa1 = sa; g.sw1 = sw; g.sc1 = sc;
+  g.c_hi = c; g.c_lo = il ? c + SER_IL_GROUP : nullptr; g.ldc = N;
+  return ser_launch_gemm_bf16(g, (hipStream_t)stream);
 }
 
 // Per-launch HIP-event timing of the encoder GEMM kernel.  start: begin recording; stop: synchronise

@@ -74,6 +74,19 @@ SER_DEVFN void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
   lo = pack_bf16x2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
+// ---- interleaved split planes ("il" layout) -----------------------------------------------------------------------
+// A split tensor x = hi + lo is stored either as two separate planes (planar) or as ONE array in which every run of
+// 32 elements is followed by its 32 lo elements: [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63 | ...].  A 128-byte line of
+// a K-contiguous row then holds everything the three-product MFMA step needs for 32 values of k, so the GEMM stages the
+// same bytes per k-tile as the single-product bf16 kernel and issues 3 MFMAs instead of 2 on them.
+// Convention (internal and at the C ABI): a plane pair with lo == hi + 32 elements IS the interleaved layout; flat
+// element offsets (row * D + col with D % 32 == 0) map by il_off(), hi and lo share the mapped offset.
+#define SER_IL_GROUP 32
+static __host__ __device__ __forceinline__ bool ser_is_il(const void* hi, const void* lo) {
+  return lo != nullptr && (const char*)lo == (const char*)hi + 2 * SER_IL_GROUP;
+}
+static __host__ __device__ __forceinline__ long long ser_il_off(long long off) { return off + (off & ~(long long)(SER_IL_GROUP - 1)); }
+
 // erf-GELU, x * Phi(x), with Phi(x) = 1/2 erfc(-x / sqrt 2) from the 5-term rational/exponential form
 // (Abramowitz & Stegun 7.1.26, |erf error| <= 1.5e-7): 2 transcendental + ~14 plain VALU instructions instead of the
 // ~40 of libm's erff, which made the GELU epilogues VALU-bound.  Measured in fp32 over [-12, 12]:

@@ -1,0 +1,147 @@
+"""GPU parity of the interleaved split-plane layout (csrc/ser_common.h: [hi 0..31 | lo 0..31 | hi 32..63 | ...]) that the
+three-product encoder kernels read and write: every producer / consumer against its planar form (bit for bit: the
+layout changes where bytes live, not the arithmetic) and the GEMM against a float64 product."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import ser_amd  # noqa: F401
+    import ser_amd._lib as lib
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return lib
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_split_interleaved_equals_planar(L):
+    x = _rand(77, 96, seed=1).cuda()
+    hi, lo = L.split_bf16(x)
+    il = L.split_bf16_il(x)
+    assert il.shape == (77, 192)
+    h2, l2 = L.il_planes(il)
+    assert torch.equal(h2, hi) and torch.equal(l2, lo)
+    # layout spelled out: 32 hi values, then their 32 lo values
+    assert torch.equal(il[:, :32], hi[:, :32]) and torch.equal(il[:, 32:64], lo[:, :32]) and torch.equal(il[:, 64:96], hi[:, 32:64])
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (199, 768, 768), (3184, 2304, 768), (37, 64, 512), (1, 64, 32),
+                                   (300, 3072, 768), (257, 160, 96), (3696, 768, 3072), (512, 128, 32)])
+def test_gemm_three_products_interleaved(L, M, N, K):
+    a, w = _rand(M, K, seed=2), _rand(N, K, seed=3) / np.sqrt(K)
+    bias, res = _rand(N, seed=4), _rand(M, N, seed=5)
+    a_il, w_il = L.split_bf16_il(a.cuda()), L.split_bf16_il(w.cuda())
+    c, c_il = L.gemm_bf16x3_il(a_il, w_il, bias.cuda(), L.ACT_GELU, res.cuda(), out_f32=True, out_split=True)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+    err = (c.cpu().double() - ref).abs().max().item()
+    assert err < 5e-5, f"max abs err {err}"
+    ch, cl = L.il_planes(c_il)
+    assert torch.equal(ch, c.to(torch.bfloat16)), "hi plane of the output is the rounded result"
+    assert ((ch.float() + cl.float()).cpu() - c.cpu()).abs().max().item() < 1e-4
+    if K % 64 == 0:      # the planar kernel multiplies the same products in the same order: identical bits
+        ah, al = L.split_bf16(a.cuda())
+        wh, wl = L.split_bf16(w.cuda())
+        c2, _, _ = L.gemm_bf16_nt(ah, al, wh, wl, bias.cuda(), L.ACT_GELU, res.cuda(), out_f32=True, out_split=False)
+        assert torch.equal(c, c2), f"interleaved vs planar differ by {(c - c2).abs().max().item()}"
+
+
+@pytest.mark.parametrize("bm", [64, 96, 128, 160, 192])
+def test_gemm_interleaved_tile_heights_agree(L, bm):
+    M, N, K = 3696, 2304, 768
+    a, w = _rand(M, K, seed=6), _rand(N, K, seed=7) / np.sqrt(K)
+    a_il, w_il = L.split_bf16_il(a.cuda()), L.split_bf16_il(w.cuda())
+    try:
+        L.lib.ser_debug_set_gemm_bm(0)
+        c0, _ = L.gemm_bf16x3_il(a_il, w_il)
+        L.lib.ser_debug_set_gemm_bm(bm)
+        c1, _ = L.gemm_bf16x3_il(a_il, w_il)
+        torch.cuda.synchronize()
+    finally:
+        L.lib.ser_debug_set_gemm_bm(0)
+    assert torch.equal(c0, c1)
+    assert (c1.cpu().double() - a.double() @ w.double().t()).abs().max().item() < 3e-5
+
+
+def test_layernorm_interleaved_output(L):
+    x, g, b = _rand(203, 768, seed=8).cuda(), _rand(768, seed=9).cuda(), _rand(768, seed=10).cuda()
+    y, yh, yl = L.layernorm(x, g, b, 1e-5, out_split=True)
+    y2 = torch.empty_like(x)
+    il = torch.empty(203, 1536, dtype=torch.bfloat16, device="cuda")
+    hi, lo = L.il_ptrs(il)
+    L.check(L.lib.ser_layernorm(x.data_ptr(), None, g.data_ptr(), b.data_ptr(), 1e-5, 203, 768, y2.data_ptr(), hi, lo, L.stream_ptr()))
+    h2, l2 = L.il_planes(il)
+    assert torch.equal(y, y2) and torch.equal(h2, yh) and torch.equal(l2, yl)
+
+
+def _attention_reference(qkv, mask, B, S, heads):
+    H = heads * 64
+    q, k, v = (qkv.double()[:, i * H:(i + 1) * H].reshape(B, S, heads, 64).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(2, 3) / 8.0
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :] == 0, float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H)
+
+
+@pytest.mark.parametrize("S,masked", [(199, False), (32, True), (70, True), (149, True), (224, False), (17, True), (225, False), (499, True)])
+def test_self_attention_interleaved(L, S, masked):
+    """Interleaved planes in and out.  S <= 224 takes the resident-K/V kernel (swapped QK^T, transposed V reads), longer
+    sequences the chunked online-softmax kernel; both against float64, and the resident kernel against the chunked one."""
+    B, heads = 3, 4
+    H = heads * 64
+    qkv = _rand(B * S, 3 * H, seed=11)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S)
+        mask[1, S - 5:] = 0
+        mask[2, 3:9] = 0
+    ref = _attention_reference(qkv, mask, B, S, heads)
+    q_il = L.split_bf16_il(qkv.cuda())
+    mk = mask.cuda() if masked else None
+    outs = []
+    for generic in (0, 1):
+        L.lib.ser_debug_set_attention_generic(generic)
+        try:
+            c_il = torch.empty(B * S, 2 * H, dtype=torch.bfloat16, device="cuda")
+            L.check(L.lib.ser_self_attention(*L.il_ptrs(q_il), L.ptr(mk), B, S, heads, *L.il_ptrs(c_il), L.stream_ptr()))
+            torch.cuda.synchronize()
+        finally:
+            L.lib.ser_debug_set_attention_generic(0)
+        h2, l2 = L.il_planes(c_il)
+        got = h2.float().cpu().double() + l2.float().cpu().double()
+        err = (got - ref).abs().max().item()
+        assert err < 5e-5, f"generic={generic}: max abs err {err}"
+        outs.append(got)
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("S,masked", [(199, False), (32, True), (100, True)])
+def test_self_attention_resident_one_plane(L, S, masked):
+    """The resident-K/V kernel in the one-product mode (hi plane only) against the chunked kernel and float64."""
+    B, heads = 2, 3
+    H = heads * 64
+    qkv = _rand(B * S, 3 * H, seed=13)
+    mask = None
+    if masked:
+        mask = torch.ones(B, S)
+        mask[1, S - 7:] = 0
+    qh, _ = L.split_bf16(qkv.cuda(), False)
+    ref = _attention_reference(qh.float().cpu(), mask, B, S, heads)
+    outs = []
+    for generic in (0, 1):
+        L.lib.ser_debug_set_attention_generic(generic)
+        try:
+            ch, _ = L.self_attention(qh, None, mask.cuda() if masked else None, B, S, heads)
+            torch.cuda.synchronize()
+        finally:
+            L.lib.ser_debug_set_attention_generic(0)
+        assert (ch.float().cpu().double() - ref).abs().max().item() < 2e-2
+        outs.append(ch.float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-2
