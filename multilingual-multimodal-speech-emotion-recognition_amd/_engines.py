@@ -205,6 +205,9 @@ class XlmrEngine:
 # changes speed only.  Skipped during graph capture (the eager warm-up pass has already run it) and in bf16x3 mode.
 _TUNED = set()
 TILE_HEIGHTS = (64, 96, 128, 160, 192)
+# interleaved three-product mode: also the single-LDS-buffer tiles (3000 + rows: three workgroups per CU) and the
+# 512-thread tiles (csrc/ser_common.h SER_GEMM_CFG_*); which wins depends on the shape (scripts/gemm_il_probe.py --cfgs)
+TILE_CONFIGS_X3 = TILE_HEIGHTS + (3064, 3096, 3128, 1192, 1256, 5128, 6256)
 
 
 def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
@@ -225,7 +228,9 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
         lo = (lambda t: t.data_ptr() + 2 * L.IL_GROUP) if three_products else (lambda t: None)
         best, best_ms = 0, float("inf")
         try:
-            for bm in TILE_HEIGHTS:
+            for bm in (TILE_CONFIGS_X3 if three_products else TILE_HEIGHTS):
+                if bm in (1192, 1256, 5128) and N < 256:
+                    continue
                 L.lib.ser_debug_set_gemm_bm(bm)
 
                 def run():

@@ -82,6 +82,9 @@ struct LnProb {
   int rows, D;
   float* y;
   bf16_t *yhi, *ylo;
+  int nsl;                 // input = x + slabs 1 .. nsl-1 (split-K partial sums, `sstride` elements apart) + bias + x2
+  long long sstride;
+  const float* bias;
 };
 
 template <int NV>  // float4 chunks per lane
@@ -105,6 +108,14 @@ SER_DEVFN void ln_row(const LnProb& P, const int row, const int lane) {
     const int c = lane + 64 * i;
     if (c < nchunk) {
       v[i] = *(const float4*)(xr + c * 4);
+      for (int sl = 1; sl < P.nsl; ++sl) {      // split-K slabs of the producing GEMM, summed in slab order
+        const float4 w = *(const float4*)(xr + sl * P.sstride + c * 4);
+        v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
+      }
+      if (P.bias) {
+        const float4 w = *(const float4*)(P.bias + c * 4);
+        v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
+      }
       if (x2r) {
         const float4 w = *(const float4*)(x2r + c * 4);
         v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
@@ -172,8 +183,24 @@ int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, co
   if (rows <= 0) return SER_OK;
   dim3 grid(ceil_div(rows, 4)), block(256);
   const int nv = ceil_div(D / 4, 64);
-  const LnProb P{x, x2, gamma, beta, eps, rows, D, y, yhi, ylo};
+  const LnProb P{x, x2, gamma, beta, eps, rows, D, y, yhi, ylo, 1, 0, nullptr};
   switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, P); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, P); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, P); break;
+    default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, P); break;
+  }
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+int ser_launch_layernorm_ex(const SerLnArgs& a, hipStream_t st) {
+  SER_REQUIRE(a.D % 4 == 0 && a.D >= 4 && a.D <= 1024, "layernorm: D=%d unsupported (need D %% 4 == 0, D <= 1024)", a.D);
+  SER_REQUIRE(!ser_is_il(a.yhi, a.ylo) || a.D % SER_IL_GROUP == 0, "layernorm: interleaved output planes need D %% %d == 0", SER_IL_GROUP);
+  if (a.rows <= 0) return SER_OK;
+  const LnProb P{a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo, a.nsl < 1 ? 1 : a.nsl, a.sstride, a.bias};
+  dim3 grid(ceil_div(a.rows, 4)), block(256);
+  switch (ceil_div(a.D / 4, 64)) {
     case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, P); break;
     case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, P); break;
     case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, P); break;
@@ -185,13 +212,13 @@ int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, co
 
 int ser_launch_layernorm_pair(const SerLnArgs& a, const SerLnArgs& b, hipStream_t st) {
   if (a.D != b.D || a.rows <= 0 || b.rows <= 0) {
-    SER_TRY(ser_launch_layernorm(a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo, st));
-    return ser_launch_layernorm(b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo, st);
+    SER_TRY(ser_launch_layernorm_ex(a, st));
+    return ser_launch_layernorm_ex(b, st);
   }
   SER_REQUIRE(a.D % 4 == 0 && a.D >= 4 && a.D <= 1024, "layernorm: D=%d unsupported", a.D);
   SER_REQUIRE(!(ser_is_il(a.yhi, a.ylo) || ser_is_il(b.yhi, b.ylo)) || a.D % SER_IL_GROUP == 0, "layernorm: interleaved output planes need D %% %d == 0", SER_IL_GROUP);
-  const LnProb P0{a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo};
-  const LnProb P1{b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo};
+  const LnProb P0{a.x, a.x2, a.gamma, a.beta, a.eps, a.rows, a.D, a.y, a.yhi, a.ylo, a.nsl < 1 ? 1 : a.nsl, a.sstride, a.bias};
+  const LnProb P1{b.x, b.x2, b.gamma, b.beta, b.eps, b.rows, b.D, b.y, b.yhi, b.ylo, b.nsl < 1 ? 1 : b.nsl, b.sstride, b.bias};
   dim3 grid(ceil_div(a.rows + b.rows, 4)), block(256);
   switch (ceil_div(a.D / 4, 64)) {
     case 1: hipLaunchKernelGGL(layernorm_pair_kernel<1>, grid, block, 0, st, P0, P1); break;

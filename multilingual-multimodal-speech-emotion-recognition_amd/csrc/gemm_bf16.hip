@@ -44,23 +44,23 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // The per-lane part of the source address is a 32-bit byte offset computed ONCE per tile (stage_offsets); per k-tile
 // only the wave-uniform base moves.  That keeps the address VGPRs of in-flight LDS-DMA instructions untouched, so
 // the compiler has no reason to drain the DMA queue (vmcnt(0)) before issuing the next stage.
-template <int R>
-SER_DEVFN void stage_offsets(unsigned (&off)[R / 32], long long ld, int row0, int rmax, int wave, int lane) {
+template <int R, int NW = 4>
+SER_DEVFN void stage_offsets(unsigned (&off)[R / (8 * NW)], long long ld, int row0, int rmax, int wave, int lane) {
   const int r = lane >> 3;
   const int c = (lane & 7) ^ r;   // source chunk for LDS chunk position lane&7 of row r
 #pragma unroll
-  for (int i = 0; i < R / 32; ++i) {
-    const int p = wave + 4 * i;
+  for (int i = 0; i < R / (8 * NW); ++i) {
+    const int p = wave + NW * i;
     int row = row0 + p * 8 + r;
     row = row < rmax ? row : rmax;
     off[i] = (unsigned)(((long long)row * ld + c * 8) * 2);
   }
 }
-template <int R>
-SER_DEVFN void stage_tile(const bf16_t* __restrict__ base_k, const unsigned (&off)[R / 32], char* lds_tile, int wave) {
+template <int R, int NW = 4>
+SER_DEVFN void stage_tile(const bf16_t* __restrict__ base_k, const unsigned (&off)[R / (8 * NW)], char* lds_tile, int wave) {
 #pragma unroll
-  for (int i = 0; i < R / 32; ++i) {      // constant trip count: no scalar branches between the LDS-DMA issues
-    const int p = wave + 4 * i;
+  for (int i = 0; i < R / (8 * NW); ++i) {      // constant trip count: no scalar branches between the LDS-DMA issues
+    const int p = wave + NW * i;
     const char* src = (const char*)base_k + off[i];
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + p * 1024), 16, 0, 0);
   }
@@ -85,19 +85,40 @@ SER_DEVFN float act_const(float v) {
 
 enum { M_BF16 = 0, M_X3P = 1, M_X3I = 2 };
 
-template <int BM, int BN, int MODE, int NS = 2>
+// Waves form a WR x WC grid over the BM x BN tile (wave tile (BM/WR) x (BN/WC)).  2 x 2 (256 threads) is the classic
+// form, two workgroups per CU; 2 x 4 (512 threads, BN = 256, one workgroup per CU, two waves per SIMD) halves the bytes
+// staged per MFMA: on this chip a CU takes in ~45-58 GB/s through global->LDS whatever the L2 hit rate
+// (scripts/gemm_il_probe.py), so the tile's area / perimeter ratio, not the MFMA rate, bounds a 128-wide tile.
+template <int P, int NP, class F>
+SER_DEVFN void static_for(F&& f) {
+  if constexpr (P < NP) {
+    f(std::integral_constant<int, P>{});
+    static_for<P + 1, NP>(f);
+  }
+}
+
+template <int BM, int BN, int MODE, int NS = 2, int WR = 2, int WC = 2>
 struct GemmCfg {
+  static constexpr int NW = WR * WC, NT = 64 * NW;
   static constexpr int NPL = MODE == M_X3P ? 2 : 1;          // LDS images per operand
   static constexpr int A_TILE = BM * ROW_BYTES, W_TILE = BN * ROW_BYTES;
   static constexpr int STAGE = (A_TILE + W_TILE) * NPL;
-  static constexpr int EPI_BYTES = (BM / 2) * (BN + 4) * 4;  // fp32 HALF tile staged for the coalesced epilogue (two passes)
+  // rows per epilogue pass: a wave-row's rows in one pass when its fp32 image fits the staging LDS, else half of them
+  // (a pass never straddles two wave-rows)
+  static constexpr int EPR = (BM / WR) * (BN + 4) * 4 <= (NS < 2 ? 2 : NS) * STAGE || NW == 4 ? BM / WR : BM / WR / 2;
+  static_assert((BM / WR) % EPR == 0 && EPR % 16 == 0, "epilogue pass rows");
+  static constexpr int EPI_BYTES = EPR * (BN + 4) * 4;        // fp32 rows staged for the coalesced epilogue
   static constexpr int LDS_RAW = NS * STAGE > EPI_BYTES ? NS * STAGE : EPI_BYTES;
-  static constexpr int GLDS = (BM / 32 + BN / 32) * NPL;       // LDS-DMA instructions per stage per wave
+  static constexpr int GLDS = (BM / (8 * NW) + BN / (8 * NW)) * NPL;       // LDS-DMA instructions per stage per wave
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && (BM / WR) % 16 == 0 && (BN / WC) % 16 == 0, "tile / wave grid");
   // leave >= 24 KB of every CU's 160 KB LDS unclaimed: the head kernels of the previous batch run beside these
   // GEMMs on another stream, and a small workgroup that cannot get LDS waits for a whole GEMM workgroup to retire
   static constexpr int LDS_BYTES = LDS_RAW <= 32 * 1024 ? 34 * 1024 : LDS_RAW;
   // register budget: where LDS lets two workgroups share a CU, VGPRs + AGPRs must stay within 256 per lane
-  static constexpr int WG_PER_CU = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;
+  // single-buffer form: three workgroups per CU (four for the 64-row tile) — set by registers (<= 168 / 128 per lane)
+  static constexpr int WG_PER_CU = NS == 1 ? (BM <= 64 ? 4 : 3) : (2 * LDS_BYTES <= 160 * 1024 ? 2 : 1);
+  static_assert(NS != 1 || WG_PER_CU * LDS_BYTES <= 160 * 1024, "single-buffer form: LDS");
+  static constexpr int WAVES_PER_SIMD = WG_PER_CU * NW / 4;   // __launch_bounds__ second argument
 };
 
 // one output tile; `bid` = tile index inside the (clip, group) batch entry `bz`
@@ -108,21 +129,23 @@ SER_DEVFN void wait_dma_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int MODE, int NS = 2>
-SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, char* lds) {
+template <int BM, int BN, int MODE, int NS = 2, int WR = 2, int WC = 2>
+SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, char* lds, const int ksl = 0) {
   constexpr bool X3 = MODE == M_X3P, IL = MODE == M_X3I;
-  constexpr int NPL = GemmCfg<BM, BN, MODE, NS>::NPL;
-  constexpr int A_TILE = GemmCfg<BM, BN, MODE, NS>::A_TILE, W_TILE = GemmCfg<BM, BN, MODE, NS>::W_TILE;
-  constexpr int STAGE = GemmCfg<BM, BN, MODE, NS>::STAGE;
-  constexpr int GLDS = GemmCfg<BM, BN, MODE, NS>::GLDS;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  using Cfg = GemmCfg<BM, BN, MODE, NS, WR, WC>;
+  constexpr int NW = Cfg::NW, NT = Cfg::NT;
+  constexpr int NPL = Cfg::NPL;
+  constexpr int A_TILE = Cfg::A_TILE, W_TILE = Cfg::W_TILE;
+  constexpr int STAGE = Cfg::STAGE;
+  constexpr int GLDS = Cfg::GLDS;
+  constexpr int WM = BM / WR, WN = BN / WC, TM = WM / 16, TN = WN / 16;
   constexpr int PM = IL ? 2 : 1;                    // physical elements per logical element along K (interleaved: hi + lo)
   constexpr int KT = IL ? 32 : 64;                  // values of k per k-tile (a k-tile is always 128 B per row)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WC, wn = wave % WC;
 
   // blockIdx -> tile: (1) XCD-contiguous chunks (blocks b, b+8, ... share an XCD's L2, so give each XCD a
   // contiguous run of tiles), (2) inside a run, GROUP_M x tiles_n super-tiles so the ~32 workgroups resident on
@@ -155,28 +178,70 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = g.K / KT;
-  unsigned offa[BM / 32], offw[BN / 32];
-  stage_offsets<BM>(offa, (long long)g.lda * PM, m0, g.M - 1, wave, lane);
-  stage_offsets<BN>(offw, (long long)g.ldw * PM, n0, g.N - 1, wave, lane);
+  // split-K: slice ksl of g.ksplit takes k-tiles [k0, k0 + nk) and writes its partial sums to slab ksl of c_f32
+  int nk = g.K / KT, k0 = 0;
+  if (g.ksplit > 1) {
+    const int per = (nk + g.ksplit - 1) / g.ksplit;
+    k0 = ksl * per;
+    nk = min(per, nk - k0);
+  }
+  unsigned offa[BM / (8 * NW)], offw[BN / (8 * NW)];
+  stage_offsets<BM, NW>(offa, (long long)g.lda * PM, m0, g.M - 1, wave, lane);
+  stage_offsets<BN, NW>(offw, (long long)g.ldw * PM, n0, g.N - 1, wave, lane);
   auto stage = [&](int kt, int buf) {
     if (SER_GEMM_DIAG & 4) return;
     char* s = lds + buf * STAGE;
-    stage_tile<BM>(a_hi + kt * BK, offa, s, wave);
-    stage_tile<BN>(w_hi + kt * BK, offw, s + A_TILE * NPL, wave);
+    stage_tile<BM, NW>(a_hi + (k0 + kt) * BK, offa, s, wave);
+    stage_tile<BN, NW>(w_hi + (k0 + kt) * BK, offw, s + A_TILE * NPL, wave);
     if (X3) {
-      stage_tile<BM>(a_lo + kt * BK, offa, s + A_TILE, wave);
-      stage_tile<BN>(w_lo + kt * BK, offw, s + A_TILE * NPL + W_TILE, wave);
+      stage_tile<BM, NW>(a_lo + (k0 + kt) * BK, offa, s + A_TILE, wave);
+      stage_tile<BN, NW>(w_lo + (k0 + kt) * BK, offw, s + A_TILE * NPL + W_TILE, wave);
     }
   };
 
+  const int fr = lane & 15, fq = lane >> 4;
+  if constexpr (NS == 1) {
+    // ONE LDS buffer: the registers are the second buffer.  Per k-tile: wait for the tile, barrier, read EVERY fragment
+    // of the tile into registers, barrier, refill the same buffer with the next k-tile, then the MFMAs run under the
+    // DMA.  Half the LDS of the double-buffered form, so three workgroups share a CU and three k-tiles per CU are in
+    // flight on the global->LDS path, whose round trip (not the MFMA rate) bounds the two-buffer loop.
+    static_assert(IL, "single-buffer form: interleaved three-product mode only");
+    if (nk > 0) stage(0, 0);
+    const char* sa = lds + wm * WM * ROW_BYTES;
+    const char* sw = lds + A_TILE + wn * WN * ROW_BYTES;
+    for (int kt = 0; kt < nk; ++kt) {
+      wait_dma_barrier<0>();
+      bf16x8 bh[TN], bl[TN], ah[TM], al[TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = lds_frag(sw, j * 16 + fr, fq);
+        bl[j] = lds_frag(sw, j * 16 + fr, 4 + fq);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = lds_frag(sa, i * 16 + fr, fq);
+        al[i] = lds_frag(sa, i * 16 + fr, 4 + fq);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) stage(kt + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  } else {
   // NS LDS buffers, NS-1 k-tiles in flight.  Tile kt is retired by a COUNTED wait (the younger tiles stay in flight
   // across the barrier), the barrier makes every wave's part of it visible, and the buffer read in the previous
   // iteration is refilled right after the barrier.  With NS = 2 this is the classic double buffer (vmcnt(0)).
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < nk) stage(s0, s0);
-  const int fr = lane & 15, fq = lane >> 4;
   int rbuf = 0, wbuf = NS - 1;
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = nk - 1 - kt;                     // tiles issued after kt (capped at NS-2 by construction)
@@ -203,8 +268,9 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
         al[0] = lds_frag(sa, fr, 4 + fq);
       }
       __builtin_amdgcn_sched_barrier(0);
+      // the whole next stage goes out in one burst, as early as possible: the loop is bound by the global->LDS round
+      // trip (1.5-2 us under load), and issuing the pieces one group per MFMA row block instead measured 1-20 % slower
       if (kt + NS - 1 < nk) stage(kt + NS - 1, wbuf);
-      wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
       __builtin_amdgcn_sched_barrier(0);
       if (RUN) {
 #pragma unroll
@@ -223,6 +289,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
     } else {
     // Fragment reads are software-pipelined by hand: the ds_read_b128s of k-step ks+1 are issued after the first MFMA
     // rows of k-step ks and pinned there (sched_barrier: nothing is scheduled across it), so they land under the
@@ -273,11 +340,13 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     }
     }
   }
+  }   // NS > 1
 
-  // epilogue: accumulators -> LDS (row-major fp32 half tile) -> coalesced 16-byte global stores, in two passes: the
-  // rows of wave-row 0, then those of wave-row 1 (the staging area is half a tile, so tall tiles keep 2 workgroups per CU).
-  // C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
+  // epilogue: accumulators -> LDS (row-major fp32 rows) -> coalesced 16-byte global stores, in BM / EPR passes of EPR rows
+  // (the classic 2 x 2 form: the rows of wave-row 0, then those of wave-row 1; the staging area is at most half a tile, so
+  // tall tiles keep 2 workgroups per CU).  C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
   constexpr int LDT = BN + 4;                       // floats; +4 keeps the two half-waves on different banks
+  constexpr int EPR = Cfg::EPR, IPP = EPR / 16, NPASS = BM / EPR;
   float* tile = (float*)lds;
   if (SER_GEMM_DIAG & 1) {                          // probe: keep the accumulators alive, store (almost) nothing
     float sacc = 0.f;
@@ -289,39 +358,43 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     return;
   }
 
-  const long long coff = b1 * g.sc1 + b2 * g.sc2;
-  const float* bias = g.bias ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
-  const float* res = g.residual ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
+  const bool partial = g.ksplit > 1;                // split-K slice: raw partial sums to its fp32 slab, nothing else
+  const long long coff = b1 * g.sc1 + b2 * g.sc2 + (partial ? (long long)ksl * g.slab_stride : 0);
+  const float* bias = (g.bias && !partial) ? g.bias + b1 * g.sbias1 + b2 * g.sbias2 : nullptr;
+  const float* res = (g.residual && !partial) ? g.residual + b1 * g.sr1 + b2 * g.sr2 : nullptr;
+  const int act = partial ? SER_ACT_NONE : g.act;
   const bool c_il = ser_is_il(g.c_hi, g.c_lo);      // interleaved output planes: one array, offsets mapped by ser_il_off
   constexpr int TPR = BN / 8;                        // threads per row, 8 columns each
-  constexpr int RPI = 256 / TPR;                     // rows per iteration
+  constexpr int RPI = NT / TPR;                      // rows per iteration
   const int tc = (tid % TPR) * 8, tr = tid / TPR;
   const int n = n0 + tc;
   const bool vec = (n + 7 < g.N) && ((g.ldc & 7) == 0) && ((coff & 7) == 0);
   float bv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bv[e] = (bias && n + e < g.N) ? bias[n + e] : 0.f;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  static_for<0, NPASS>([&](auto pass_tag) {
+  constexpr int pass = decltype(pass_tag)::value;
+  constexpr int owner = (pass * EPR) / WM;           // wave-row whose accumulators hold these rows
+  constexpr int i0 = ((pass * EPR) % WM) / 16;       // compile-time accumulator indices: acc stays in registers
   __syncthreads();                                   // k-loop reads (first pass) / previous pass's reads are done
-  if (wm == half) {
+  if (wm == owner) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int ii = 0; ii < IPP; ++ii)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tile[(i * 16 + fq * 4 + r) * LDT + wn * WN + j * 16 + fr] = acc[i][j][r];
+        for (int r = 0; r < 4; ++r) tile[(ii * 16 + fq * 4 + r) * LDT + wn * WN + j * 16 + fr] = acc[i0 + ii][j][r];
   }
   __syncthreads();
 #pragma unroll 2
-  for (int rr = tr; rr < WM; rr += RPI) {
-    const int m = m0 + half * WM + rr;
+  for (int rr = tr; rr < EPR; rr += RPI) {
+    const int m = m0 + pass * EPR + rr;
     if (m >= g.M || n >= g.N) continue;
     float v[8];
     const float4 t0 = *(const float4*)(tile + rr * LDT + tc), t1 = *(const float4*)(tile + rr * LDT + tc + 4);
     v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], g.act);
+    for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e] + bv[e], act);
     const long long o = coff + (long long)m * g.ldc + n;
     const long long op = c_il ? ser_il_off(o) : o;   // plane offset (8 consecutive columns never straddle a 32-group)
     if (SER_GEMM_DIAG & 8) {
@@ -343,7 +416,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
         *(float4*)(g.c_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)(g.c_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
       }
-      if (g.c_hi) {
+      if (g.c_hi && !partial) {
         uint32_t ph[4], pl[4];
         if (g.c_lo) {
 #pragma unroll
@@ -362,7 +435,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
         float x = v[e];
         if (res) x += res[(long long)m * g.ldr + n + e];
         if (g.c_f32) g.c_f32[o + e] = x;
-        if (g.c_hi) {
+        if (g.c_hi && !partial) {
           bf16_t h, l;
           split_bf16(x, h, l);
           const long long oe = c_il ? ser_il_off(o + e) : o + e;
@@ -372,18 +445,22 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
       }
     }
   }
-  }   // half
+  });   // pass
 }
 
 // Persistent launch: the grid never exceeds what is resident at once (gridDim.x <= 2 workgroups per CU), each
 // workgroup walks tiles `blockIdx.x, blockIdx.x + gridDim.x, ...` of the flattened (batch entry, tile) space.  No tile
 // ever waits in the dispatcher's queue, so the small head kernels of the other stream are placed as soon as they
 // arrive instead of behind this kernel's not-yet-dispatched workgroups.
-template <int BM, int BN, int MODE, int NS = 2>
-__global__ __launch_bounds__(256, (GemmCfg<BM, BN, MODE, NS>::WG_PER_CU)) void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
-  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS>::LDS_BYTES];
-  for (int w = blockIdx.x; w < total; w += gridDim.x) {
-    gemm_tile<BM, BN, MODE, NS>(g, w % tiles, w / tiles, lds);
+template <int BM, int BN, int MODE, int NS = 2, int WR = 2, int WC = 2>
+__global__ __launch_bounds__((GemmCfg<BM, BN, MODE, NS, WR, WC>::NT), (GemmCfg<BM, BN, MODE, NS, WR, WC>::WAVES_PER_SIMD))
+void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) {
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS, WR, WC>::LDS_BYTES];
+  // flattened work space: (split-K slice, batch entry, tile); the slices of a tile are adjacent block ids
+  const int ks = g.ksplit > 1 ? g.ksplit : 1;
+  for (int w = blockIdx.x; w < total * ks; w += gridDim.x) {
+    const int t = w / ks;
+    gemm_tile<BM, BN, MODE, NS, WR, WC>(g, t % tiles, t / tiles, lds, w % ks);
     __syncthreads();     // the epilogue's LDS tile is dead before the next tile's first stage lands
   }
 }
@@ -391,15 +468,18 @@ __global__ __launch_bounds__(256, (GemmCfg<BM, BN, MODE, NS>::WG_PER_CU)) void g
 // Two independent problems in one launch (the layer-l GEMMs of Wav2Vec2 and of XLM-R have no dependence on each
 // other): the tiles of the small problem come first in the grid, so they start at once and ride along with the
 // large one instead of queueing, launch after launch, on a second stream behind it.
-template <int BM, int BN, int MODE, int NS = 2>
-__global__ __launch_bounds__(256, (GemmCfg<BM, BN, MODE, NS>::WG_PER_CU)) void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0,
-                                                             const int tiles0, const int tiles1) {
-  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS>::LDS_BYTES];
+template <int BM, int BN, int MODE, int NS = 2, int WR = 2, int WC = 2>
+__global__ __launch_bounds__((GemmCfg<BM, BN, MODE, NS, WR, WC>::NT), (GemmCfg<BM, BN, MODE, NS, WR, WC>::WAVES_PER_SIMD))
+void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0, const int tiles0, const int tiles1) {
+  __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS, WR, WC>::LDS_BYTES];
   // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches
   const bool first = (int)blockIdx.x < total0;
   const SerGemmArgs* g = first ? &g0 : &g1;
+  // total0 / tiles0 / tiles1 count (tile, split-K slice) pairs when the problems are split (both with the same factor)
+  const int ks = g0.ksplit > 1 ? g0.ksplit : 1;
   const int w = first ? blockIdx.x : blockIdx.x - total0, tiles = first ? tiles0 : tiles1;
-  gemm_tile<BM, BN, MODE, NS>(*g, w % tiles, w / tiles, lds);
+  const int t = w / ks;
+  gemm_tile<BM, BN, MODE, NS, WR, WC>(*g, t % tiles, t / tiles, lds, w % ks);
 }
 
 // ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
@@ -442,99 +522,94 @@ static int gemm_mode(const SerGemmArgs& g) {
   return (ser_is_il(g.a_hi, g.a_lo) && ser_is_il(g.w_hi, g.w_lo)) ? M_X3I : M_X3P;
 }
 
+struct ProfScope {       // HIP events around one launch when bench.py's roofline leg is recording
+  ProfRec rec;
+  bool on;
+  hipStream_t st;
+  int begin(double flops, hipStream_t s) {
+    on = g_prof_on; st = s;
+    if (!on) return SER_OK;
+    SER_CHECK_HIP(hipEventCreate(&rec.e0));
+    SER_CHECK_HIP(hipEventCreate(&rec.e1));
+    rec.flops = flops;
+    SER_CHECK_HIP(hipEventRecord(rec.e0, st));
+    return SER_OK;
+  }
+  int end() {
+    if (!on) return SER_OK;
+    SER_CHECK_HIP(hipEventRecord(rec.e1, st));
+    g_prof.push_back(rec);
+    return SER_OK;
+  }
+};
+static double gemm_flops(const SerGemmArgs& g) { return 2.0 * g.M * (double)g.N * g.K * g.nb1 * g.nb2; }   // algorithmic
+
+// one problem, or two (small first) in the paired kernel; WR x WC waves
+template <int BM, int BN, int MODE, int NS, int WR, int WC>
+static int launch_kernel(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  using Cfg = GemmCfg<BM, BN, MODE, NS, WR, WC>;
+  const int ks = big.ksplit > 1 ? big.ksplit : 1;
+  const int tiles1 = ceil_div(big.M, BM) * ceil_div(big.N, BN), total1 = tiles1 * big.nb1 * big.nb2;
+  ProfScope ps;
+  if (small) {
+    const int tiles0 = ceil_div(small->M, BM) * ceil_div(small->N, BN), total0 = tiles0 * small->nb1 * small->nb2;
+    SER_TRY(ps.begin(gemm_flops(*small) + gemm_flops(big), st));
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, NS, WR, WC>), dim3((total0 + total1) * ks), dim3(Cfg::NT), g_gemm_lds_pad, st,
+                       *small, big, total0 * ks, tiles0, tiles1);
+  } else {
+    const int cap = g_gemm_persist_cap > 0 ? g_gemm_persist_cap : total1 * ks;
+    SER_TRY(ps.begin(gemm_flops(big), st));
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE, NS, WR, WC>), dim3(total1 * ks < cap ? total1 * ks : cap), dim3(Cfg::NT),
+                       g_gemm_lds_pad, st, big, tiles1, total1);
+  }
+  SER_TRY(ps.end());
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+// classic 2 x 2 wave grid, LDS stages from the per-shape table
 template <int BM, int BN, int MODE>
-static void launch_nt_mode(const SerGemmArgs& g, dim3 grid, int tiles, int total, hipStream_t st) {
-  dim3 block(256);
+static int launch_stages(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
   if constexpr (MODE == M_X3P) {
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    return launch_kernel<BM, BN, MODE, 2, 2, 2>(small, big, st);
   } else {
     const int ns = stages_for<BM, BN>();
-    if (ns == 3)
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE, 3>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
-    else if (ns == 4 && BM * BN <= 64 * 128)
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
-    else
-      hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, g, tiles, total);
+    if (ns == 3) return launch_kernel<BM, BN, MODE, 3, 2, 2>(small, big, st);
+    if (ns == 4 && BM * BN <= 64 * 128) return launch_kernel<BM, BN, MODE, (BM * BN <= 64 * 128 ? 4 : 2), 2, 2>(small, big, st);
+    return launch_kernel<BM, BN, MODE, 2, 2, 2>(small, big, st);
   }
 }
 
 template <int BM, int BN>
-int launch_cfg(const SerGemmArgs& g, hipStream_t st) {
-  const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-  const int total = tiles * g.nb1 * g.nb2;
-  const int cap = g_gemm_persist_cap > 0 ? g_gemm_persist_cap : total;
-  dim3 grid(total < cap ? total : cap);
-  ProfRec rec;
-  if (g_prof_on) {
-    SER_CHECK_HIP(hipEventCreate(&rec.e0));
-    SER_CHECK_HIP(hipEventCreate(&rec.e1));
-    rec.flops = 2.0 * g.M * (double)g.N * g.K * g.nb1 * g.nb2;   // algorithmic (one product per MAC)
-    SER_CHECK_HIP(hipEventRecord(rec.e0, st));
-  }
-  const int mode = gemm_mode(g);
+static int launch_any(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  const int mode = gemm_mode(big);
   if (mode == M_X3P) {
     constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;     // the planar form (two LDS images per operand) keeps the two classic heights
     SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the planar 3-product mode", BM);
-    launch_nt_mode<XBM, BN, M_X3P>(g, grid, tiles, total, st);
-  } else if (mode == M_X3I) {
-    launch_nt_mode<BM, BN, M_X3I>(g, grid, tiles, total, st);
-  } else {
-    launch_nt_mode<BM, BN, M_BF16>(g, grid, tiles, total, st);
+    return launch_stages<XBM, BN, M_X3P>(small, big, st);
   }
-  if (g_prof_on) {
-    SER_CHECK_HIP(hipEventRecord(rec.e1, st));
-    g_prof.push_back(rec);
-  }
-  SER_LAUNCH_CHECK();
-  return SER_OK;
+  if (mode == M_X3I) return launch_stages<BM, BN, M_X3I>(small, big, st);
+  return launch_stages<BM, BN, M_BF16>(small, big, st);
 }
-
-template <int BM, int BN, int MODE>
-static void launch_pair_mode(const SerGemmArgs& small, const SerGemmArgs& big, dim3 grid, int total0, int tiles0, int tiles1,
-                             hipStream_t st) {
-  dim3 block(256);
-  if constexpr (MODE == M_X3P) {
-    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-  } else {
-    const int ns = stages_for<BM, BN>();
-    if (ns == 3)
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, 3>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-    else if (ns == 4 && BM * BN <= 64 * 128)
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, (BM * BN <= 64 * 128 ? 4 : 2)>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-    else
-      hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE>), grid, block, g_gemm_lds_pad, st, small, big, total0, tiles0, tiles1);
-  }
-}
-
 template <int BM, int BN>
-int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) {
-  const int tiles0 = ceil_div(small.M, BM) * ceil_div(small.N, BN), tiles1 = ceil_div(big.M, BM) * ceil_div(big.N, BN);
-  const int total0 = tiles0 * small.nb1 * small.nb2, total1 = tiles1 * big.nb1 * big.nb2;
-  dim3 grid(total0 + total1);
-  ProfRec rec;
-  if (g_prof_on) {
-    SER_CHECK_HIP(hipEventCreate(&rec.e0));
-    SER_CHECK_HIP(hipEventCreate(&rec.e1));
-    rec.flops = 2.0 * small.M * (double)small.N * small.K * small.nb1 * small.nb2 +
-                2.0 * big.M * (double)big.N * big.K * big.nb1 * big.nb2;
-    SER_CHECK_HIP(hipEventRecord(rec.e0, st));
+int launch_cfg(const SerGemmArgs& g, hipStream_t st) { return launch_any<BM, BN>(nullptr, g, st); }
+template <int BM, int BN>
+int launch_pair_cfg(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st) { return launch_any<BM, BN>(&small, big, st); }
+
+// 512-thread tiles (interleaved three-product mode): 2 x 4 waves over BM x 256, 4 x 2 over 256 x 128; two LDS buffers
+static int launch_wide(int cfg, const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  SER_REQUIRE(gemm_mode(big) == M_X3I, "gemm_bf16: the 512-thread tiles are built for the interleaved three-product mode");
+  switch (cfg) {
+    case SER_GEMM_CFG_128x256: return launch_kernel<128, 256, M_X3I, 2, 2, 4>(small, big, st);
+    case SER_GEMM_CFG_192x256: return launch_kernel<192, 256, M_X3I, 2, 2, 4>(small, big, st);
+    case SER_GEMM_CFG_256x256: return launch_kernel<256, 256, M_X3I, 2, 2, 4>(small, big, st);
+    case SER_GEMM_CFG_256x128: return launch_kernel<256, 128, M_X3I, 2, 4, 2>(small, big, st);
+    case SER_GEMM_CFG_128x256_3: return launch_kernel<128, 256, M_X3I, 3, 2, 4>(small, big, st);    // three LDS buffers: two k-tiles in flight
+    case SER_GEMM_CFG_256x128_3: return launch_kernel<256, 128, M_X3I, 3, 4, 2>(small, big, st);
+    default: break;
   }
-  const int mode = gemm_mode(big);
-  if (mode == M_X3P) {
-    constexpr int XBM = (BM == 64 || BM == 128) ? BM : 128;
-    SER_REQUIRE(XBM == BM, "gemm_bf16: tile height %d is not built for the planar 3-product mode", BM);
-    launch_pair_mode<XBM, BN, M_X3P>(small, big, grid, total0, tiles0, tiles1, st);
-  } else if (mode == M_X3I) {
-    launch_pair_mode<BM, BN, M_X3I>(small, big, grid, total0, tiles0, tiles1, st);
-  } else {
-    launch_pair_mode<BM, BN, M_BF16>(small, big, grid, total0, tiles0, tiles1, st);
-  }
-  if (g_prof_on) {
-    SER_CHECK_HIP(hipEventRecord(rec.e1, st));
-    g_prof.push_back(rec);
-  }
-  SER_LAUNCH_CHECK();
-  return SER_OK;
+  ser_set_error("gemm_bf16: unknown tile configuration %d", cfg);
+  return SER_E_ARG;
 }
 
 static int gemm_check(const SerGemmArgs& g) {
@@ -549,6 +624,10 @@ static int gemm_check(const SerGemmArgs& g) {
   } else {
     SER_REQUIRE(g.K % BK == 0, "gemm_bf16: K=%d must be a multiple of %d", g.K, BK);
     SER_REQUIRE(g.lda % 8 == 0 && g.ldw % 8 == 0, "gemm_bf16: lda=%d ldw=%d must be multiples of 8", g.lda, g.ldw);
+  }
+  if (g.ksplit > 1) {
+    SER_REQUIRE(gemm_mode(g) == M_X3I && g.c_f32 && g.slab_stride > 0, "gemm_bf16: split-K needs interleaved operands and an fp32 slab area");
+    SER_REQUIRE(g.ksplit <= 8 && (g.K / 32) >= g.ksplit, "gemm_bf16: bad split-K factor %d for K=%d", g.ksplit, g.K);
   }
   if (g.c_hi && ser_is_il(g.c_hi, g.c_lo))
     SER_REQUIRE(g.ldc % SER_IL_GROUP == 0 && g.sc1 % SER_IL_GROUP == 0 && g.sc2 % SER_IL_GROUP == 0, "gemm_bf16: interleaved output needs ldc=%d and batch strides in multiples of %d", g.ldc, SER_IL_GROUP);
@@ -571,22 +650,38 @@ static int slots_per_cu() {
   const int by_lds = (160 * 1024) / lds;
   return by_lds < 1 ? 1 : (by_lds > 4 ? 4 : by_lds);
 }
-// measured choices (ser_gemm_tile_hint, filled by the engines' one-time tuning pass) take precedence over the model
-struct TileHint { long long rows; int N, K, mode, bm; };
+// measured choices (filled by the engines' one-time tuning pass) take precedence over the model.  A plan = tile
+// configuration (SER_GEMM_CFG_*: a tile height 64..192 of the 2 x 2 form, or a 512-thread tile) + split-K factor.
+struct TileHint { long long rows; int N, K, mode, cfg, ksplit; };
 static std::vector<TileHint> g_tile_hints;
-extern "C" int ser_gemm_tile_hint_mode(long long rows_total, int N, int K, int three_products, int bm) {
+extern "C" int ser_gemm_plan_set(long long rows_total, int N, int K, int three_products, int cfg, int ksplit) {
   const int mode = three_products ? M_X3I : M_BF16;
   for (auto& h : g_tile_hints)
-    if (h.rows == rows_total && h.N == N && h.K == K && h.mode == mode) { h.bm = bm; return SER_OK; }
-  g_tile_hints.push_back(TileHint{rows_total, N, K, mode, bm});
+    if (h.rows == rows_total && h.N == N && h.K == K && h.mode == mode) { h.cfg = cfg; h.ksplit = ksplit; return SER_OK; }
+  g_tile_hints.push_back(TileHint{rows_total, N, K, mode, cfg, ksplit < 1 ? 1 : ksplit});
   return SER_OK;
 }
-extern "C" int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm) { return ser_gemm_tile_hint_mode(rows_total, N, K, 0, bm); }
+extern "C" int ser_gemm_plan_get(long long rows_total, int N, int K, int three_products, int* cfg, int* ksplit) {
+  const int mode = three_products ? M_X3I : M_BF16;
+  if (cfg) *cfg = 0;
+  if (ksplit) *ksplit = 1;
+  for (const auto& h : g_tile_hints)
+    if (h.rows == rows_total && h.N == N && h.K == K && h.mode == mode) {
+      if (cfg) *cfg = h.cfg;
+      if (ksplit) *ksplit = h.ksplit < 1 ? 1 : h.ksplit;
+      return SER_OK;
+    }
+  return SER_OK;
+}
+extern "C" int ser_gemm_tile_hint_mode(long long rows_total, int N, int K, int three_products, int bm) {
+  return ser_gemm_plan_set(rows_total, N, K, three_products, bm, 1);
+}
+extern "C" int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm) { return ser_gemm_plan_set(rows_total, N, K, 0, bm, 1); }
 
 static int pick_bm(long long rows_a, long long rows_b, int N, int K, long long nb_b, int mode) {
   if (g_gemm_force_bm) return g_gemm_force_bm;
   for (const auto& h : g_tile_hints)
-    if (h.rows == rows_a + rows_b * nb_b && h.N == N && h.K == K && h.mode == mode && h.bm) return h.bm;
+    if (h.rows == rows_a + rows_b * nb_b && h.N == N && h.K == K && h.mode == mode && h.cfg) return h.cfg;
   const int cands[5] = {64, 96, 128, 160, 192};
   const int slots[5] = {slots_per_cu<64>(), slots_per_cu<96>(), slots_per_cu<128>(), slots_per_cu<160>(), slots_per_cu<192>()};
   int best = 128;
@@ -610,9 +705,25 @@ template <int BM>
 static int launch_bm(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
   return small ? launch_pair_cfg<BM, 128>(*small, big, st) : launch_cfg<BM, 128>(big, st);
 }
+// single-LDS-buffer form (fragments of a whole k-tile in registers, three workgroups per CU): 256-thread BM x 128 tiles
+static int launch_single(int cfg, const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  SER_REQUIRE(gemm_mode(big) == M_X3I, "gemm_bf16: the single-buffer tiles are built for the interleaved three-product mode");
+  switch (cfg - SER_GEMM_CFG_SINGLE) {
+    case 64: return launch_kernel<64, 128, M_X3I, 1, 2, 2>(small, big, st);
+    case 96: return launch_kernel<96, 128, M_X3I, 1, 2, 2>(small, big, st);
+    case 128: return launch_kernel<128, 128, M_X3I, 1, 2, 2>(small, big, st);
+    default: break;      // taller tiles do not fit 168 registers per lane with every fragment of a k-tile resident
+  }
+  ser_set_error("gemm_bf16: unknown tile configuration %d", cfg);
+  return SER_E_ARG;
+}
+
 static int launch_bn128(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
   const long long rows_a = small ? (long long)small->M * small->nb1 * small->nb2 : 0;
-  switch (pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2, gemm_mode(big))) {
+  const int cfg = big.cfg ? big.cfg : pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2, gemm_mode(big));
+  if (cfg >= SER_GEMM_CFG_SINGLE && cfg < SER_GEMM_CFG_SINGLE + 1000) return launch_single(cfg, small, big, st);
+  if (cfg >= SER_GEMM_CFG_WIDE) return launch_wide(cfg, small, big, st);
+  switch (cfg) {
     case 64: return launch_bm<64>(small, big, st);
     case 96: return launch_bm<96>(small, big, st);
     case 160: return launch_bm<160>(small, big, st);
@@ -626,6 +737,7 @@ int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, 
   SER_TRY(gemm_check(small));
   SER_TRY(gemm_check(big));
   SER_REQUIRE(gemm_mode(small) == gemm_mode(big), "gemm_bf16 pair: mixed precision modes");
+  SER_REQUIRE((small.ksplit > 1 ? small.ksplit : 1) == (big.ksplit > 1 ? big.ksplit : 1), "gemm_bf16 pair: the two problems must use the same split-K factor");
   const long long nb = (long long)big.nb1 * big.nb2;
   const long long t128 = (long long)ceil_div(big.M, 128) * ceil_div(big.N, 128) * nb;
   if (big.N <= 64 || small.N <= 64) {          // keep the narrow-N shape out of the pair path
@@ -695,6 +807,20 @@ extern "C" int ser_debug_gemm_batched(const uint16_t* a, const uint16_t* w, int 
   g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
   g.nb1 = nb; g.nb2 = 1; g.sa1 = sa; g.sw1 = sw; g.sc1 = sc;
   g.c_hi = c; g.c_lo = il ? c + SER_IL_GROUP : nullptr; g.ldc = N;
+  return ser_launch_gemm_bf16(g, (hipStream_t)stream);
+}
+
+// debug / probe entry: interleaved three-product GEMM with an explicit tile configuration and split-K factor;
+// c_f32 = [ksplit][M][N] slabs of raw partial sums when ksplit > 1, else the [M][N] result
+extern "C" int ser_debug_gemm_il_cfg(const uint16_t* a, const uint16_t* w, int M, int N, int K, int cfg, int ksplit, float* c_f32,
+                                     void* stream) {
+  SerGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = a; g.w_hi = w; g.a_lo = a + SER_IL_GROUP; g.w_lo = w + SER_IL_GROUP;
+  g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
+  g.nb1 = 1; g.nb2 = 1;
+  g.c_f32 = c_f32; g.ldc = N;
+  g.cfg = cfg; g.ksplit = ksplit; g.slab_stride = (long long)M * N;
   return ser_launch_gemm_bf16(g, (hipStream_t)stream);
 }
 

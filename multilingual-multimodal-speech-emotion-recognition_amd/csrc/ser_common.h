@@ -190,8 +190,17 @@ struct SerGemmArgs {
   float* c_f32;                // [M, ldc] or null
   bf16_t *c_hi, *c_lo;         // [M, ldc] planes or null
   int ldc;
+  // split-K (interleaved three-product mode): ksplit > 1 = each of ksplit slices of K writes its raw partial sums to
+  // c_f32 + slice * slab_stride (bias, activation, residual and planes are left to the consumer, which adds the slabs)
+  int ksplit;
+  long long slab_stride;
+  int cfg;                     // tile configuration id (SER_GEMM_CFG_*), 0 = let the launcher choose
 };
+// tile configurations: 64..192 = rows of a 256-thread BM x 128 tile; the 512-thread tiles:
+enum { SER_GEMM_CFG_SINGLE = 3000 /* + rows: single LDS buffer, three workgroups per CU */, SER_GEMM_CFG_WIDE = 1000, SER_GEMM_CFG_128x256 = 1128, SER_GEMM_CFG_192x256 = 1192, SER_GEMM_CFG_256x256 = 1256, SER_GEMM_CFG_256x128 = 2256,
+       SER_GEMM_CFG_128x256_3 = 5128, SER_GEMM_CFG_256x128_3 = 6256 };
 int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st);
+extern "C" int ser_gemm_plan_get(long long rows_total, int N, int K, int three_products, int* cfg, int* ksplit);
 int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st);
 int ser_launch_split(const float* x, bf16_t* hi, bf16_t* lo, long long n, hipStream_t st);
 int ser_launch_layernorm(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows,
@@ -202,8 +211,13 @@ struct SerLnArgs {
   int rows, D;
   float* y;
   bf16_t *yhi, *ylo;
+  // input = sum of `nsl` slabs x + s * sstride (split-K partial sums of the producing GEMM) + bias[D] + x2 (residual)
+  int nsl;
+  long long sstride;
+  const float* bias;
 };
 int ser_launch_layernorm_pair(const SerLnArgs& a, const SerLnArgs& b, hipStream_t st);
+int ser_launch_layernorm_ex(const SerLnArgs& a, hipStream_t st);
 struct SerAttnArgs {
   const bf16_t *qkv_hi, *qkv_lo;
   const float* key_mask;

@@ -55,10 +55,35 @@ def run_shape(name, M, N, K, il, nb=1, stride0=False, heights=HEIGHTS):
     L.lib.ser_debug_set_gemm_bm(0)
 
 
+def run_cfgs(name, M, N, K):
+    """Interleaved mode: every tile configuration x split-K factor on one shape."""
+    import ctypes as C
+    fn = L.lib.ser_debug_gemm_il_cfg
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    g = torch.Generator().manual_seed(0)
+    a = (torch.randn(M, 2 * K, generator=g) * 0.5).to("cuda", torch.bfloat16)
+    w = (torch.randn(N, 2 * K, generator=g) * 0.05).to("cuda", torch.bfloat16)
+    out = torch.empty(4, M, N, dtype=torch.float32, device="cuda")
+    cfgs = [(64, 64, 128), (96, 96, 128), (128, 128, 128), (160, 160, 128), (192, 192, 128), (3064, 64, 128), (3096, 96, 128), (3128, 128, 128)]
+    if "--wide" in sys.argv:
+        cfgs += [(1128, 128, 256), (1192, 192, 256), (1256, 256, 256), (2256, 256, 128), (5128, 128, 256), (6256, 256, 128)]
+    for cfg, bm, bn in cfgs:
+        for ks in ((1, 2, 3, 4) if N <= 1024 and "--splitk" in sys.argv else (1,)):
+            us = timed(lambda: L.check(fn(a.data_ptr(), w.data_ptr(), M, N, K, cfg, ks, out.data_ptr(), L.stream_ptr())))
+            tiles = -(-M // bm) * -(-N // bn) * ks
+            tf = 2.0 * M * N * K / us / 1e6
+            print(f"  {name:8s} M={M:6d} N={N:5d} K={K:5d} tile {bm:3d}x{bn:3d} ksplit {ks}: {us:8.1f} us  {tf:7.1f} TF  mfma-util {tf * 3 / PEAK:5.1%}  workgroups {tiles:5d}",
+                  flush=True)
+
+
 if __name__ == "__main__":
     il = "--plain" not in sys.argv
     print("mode", "interleaved three-product" if il else "one product")
-    if "--resident" in sys.argv:
+    if "--cfgs" in sys.argv:
+        for name, M, N, K in SHAPES[:6]:
+            run_cfgs(name, M, N, K)
+    elif "--resident" in sys.argv:
         for nb in (16, 64):
             run_shape("resident", 512, 512, 768, il, nb=nb, stride0=True)
             run_shape("distinct", 512, 512, 768, il, nb=nb, stride0=False)

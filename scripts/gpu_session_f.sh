@@ -1,0 +1,7 @@
+#!/bin/bash
+set -o pipefail
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout -k 10 400 python -m pytest tests/test_gpu_interleaved.py -x -q -m gpu > gpurun_out/f_ops.log 2>&1; echo "ops rc=$?"; tail -12 gpurun_out/f_ops.log
+timeout -k 10 400 python scripts/gemm_il_probe.py --cfgs > gpurun_out/f_probe_cfgs.txt 2>&1; echo "probe rc=$?"
+cat gpurun_out/f_probe_cfgs.txt

@@ -70,6 +70,51 @@ def test_gemm_interleaved_tile_heights_agree(L, bm):
     assert (c1.cpu().double() - a.double() @ w.double().t()).abs().max().item() < 3e-5
 
 
+WIDE = {"128x256": 1128, "192x256": 1192, "256x256": 1256, "256x128": 2256, "single-buffer 64": 3064, "single-buffer 96": 3096,
+        "single-buffer 128": 3128, "128x256 3 buffers": 5128, "256x128 3 buffers": 6256}
+
+
+def _gemm_cfg(L, a_il, w_il, M, N, K, cfg, ksplit=1):
+    import ctypes as C
+    fn = L.lib.ser_debug_gemm_il_cfg
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    out = torch.full((max(1, ksplit), M, N), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(fn(a_il.data_ptr(), w_il.data_ptr(), M, N, K, cfg, ksplit, out.data_ptr(), L.stream_ptr()), "ser_debug_gemm_il_cfg")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(WIDE))
+@pytest.mark.parametrize("M,N,K", [(3696, 2304, 768), (700, 768, 3072), (257, 130, 96), (6399, 512, 1536)])
+def test_gemm_512_thread_tiles_equal_the_classic_tiles(L, name, M, N, K):
+    """2 x 4 / 4 x 2 wave grids over 256-wide / 256-tall tiles: the products and their order per accumulator are those
+    of the 2 x 2 kernel, so the results are identical; ragged edges included."""
+    a, w = _rand(M, K, seed=21), _rand(N, K, seed=22) / np.sqrt(K)
+    a_il, w_il = L.split_bf16_il(a.cuda()), L.split_bf16_il(w.cuda())
+    ref = _gemm_cfg(L, a_il, w_il, M, N, K, 128)[0]
+    got = _gemm_cfg(L, a_il, w_il, M, N, K, WIDE[name])[0]
+    assert torch.equal(ref, got), f"{name}: differs by {(ref - got).abs().max().item()}"
+    assert (got.cpu().double() - a.double() @ w.double().t()).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("cfg", [64, 192, 1192, 2256])
+@pytest.mark.parametrize("ksplit", [2, 3, 4])
+def test_gemm_split_k_slabs_sum_to_the_product(L, cfg, ksplit):
+    M, N, K = 3696, 768, 3072
+    a, w = _rand(M, K, seed=23), _rand(N, K, seed=24) / np.sqrt(K)
+    a_il, w_il = L.split_bf16_il(a.cuda()), L.split_bf16_il(w.cuda())
+    slabs = _gemm_cfg(L, a_il, w_il, M, N, K, cfg, ksplit)
+    assert torch.isfinite(slabs).all(), "a slab was not written completely"
+    ref = a.double() @ w.double().t()
+    assert (slabs.double().sum(0).cpu() - ref).abs().max().item() < 5e-5
+    # every slab is the product over its own k range
+    per = -(-(K // 32) // ksplit) * 32
+    for s_ in range(ksplit):
+        part = a[:, s_ * per:(s_ + 1) * per].double() @ w[:, s_ * per:(s_ + 1) * per].double().t()
+        assert (slabs[s_].double().cpu() - part).abs().max().item() < 5e-5
+
+
 def test_layernorm_interleaved_output(L):
     x, g, b = _rand(203, 768, seed=8).cuda(), _rand(768, seed=9).cuda(), _rand(768, seed=10).cuda()
     y, yh, yl = L.layernorm(x, g, b, 1e-5, out_split=True)
