@@ -311,6 +311,10 @@ def main():
                        "schedule": "frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "
                                    "(two streams; one encoder pass and one update per step)" if pipeline else "sequential",
                        "stress_sizes": bool(args.stress),
+                       "allreduce_overlap": (None if world == 1 else
+                                             ("classifier bucket (76 of 100 MB) all-reduced over RCCL beside the backward of fusion / pooling / "
+                                              "cross-attention / adapters (head graph captured in two pieces), the rest before AdamW"
+                                              if getattr(stepper, "split", False) else "all buckets reduced after backward (no overlap)")),
                        "head_dropout": "training mode (77 nn.Dropout sites active; frozen encoders in eval semantics)"},
             "roofline": roof, "cpu_baseline": cpu,
             "logit_max_abs_err_vs_cpu_oracle": err, "class_indices_equal": same,

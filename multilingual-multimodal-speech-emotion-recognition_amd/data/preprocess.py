@@ -63,6 +63,21 @@ def load_audio(path, sr=16000, max_length=30):
         return torch.zeros(sr, dtype=torch.float32)
 
 
+def clip_length(path, sr=16000, max_length=30):
+    """Number of samples `load_audio(path)` will return, from the WAV header alone (no decoding): what the length-bucketing
+    sampler sorts by.  Unreadable files count as the 1 s of zeros load_audio substitutes."""
+    import wave
+    if not path.startswith('datasets/'):
+        path = f"datasets/{path}"
+    try:
+        with wave.open(path, "rb") as f:
+            frames, orig_sr = f.getnframes(), f.getframerate()
+        n = frames if orig_sr == sr else math.ceil(frames * sr / orig_sr)
+        return max(int(sr * 0.5), min(n, sr * max_length))
+    except Exception:  # noqa: BLE001
+        return sr
+
+
 def speed_perturb(waveform: torch.Tensor, factor: float) -> torch.Tensor:
     if abs(factor - 1.0) < 1e-3:
         return waveform
@@ -71,8 +86,8 @@ def speed_perturb(waveform: torch.Tensor, factor: float) -> torch.Tensor:
     return resample(y, mid, 16000).squeeze(0)
 
 
-def add_noise_snr(waveform: torch.Tensor, snr_db: float) -> torch.Tensor:
+def add_noise_snr(waveform: torch.Tensor, snr_db: float, generator=None) -> torch.Tensor:
     signal_power = waveform.pow(2).mean().clamp(min=1e-12)
     noise_power = (signal_power / (10 ** (snr_db / 10))).item()
-    noise = torch.randn_like(waveform) * math.sqrt(noise_power)
+    noise = torch.randn(waveform.shape, generator=generator, dtype=waveform.dtype) * math.sqrt(noise_power)
     return (waveform + noise).clamp(min=-1.0, max=1.0)

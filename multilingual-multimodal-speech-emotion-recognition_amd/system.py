@@ -125,8 +125,11 @@ class SERSystem(nn.Module):
         self._drop_state.add_(1)                                  # one launch; captured with the step, so replays advance it
         return _ops.dropout_scope(self._drop_state)
 
-    def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True):
-        """Everything trainable: adapters -> cross-attention -> pooling -> fusion -> classifier -> loss."""
+    def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True, split=False):
+        """Everything trainable: adapters -> cross-attention -> pooling -> fusion -> classifier -> loss.
+        split=True: the classifier and the loss hang off a detached copy of `fused`; returns (loss, logits, fused, leaf),
+        so that the caller can run the classifier's backward first (loss.backward(): its gradient bucket is then
+        complete and can travel over xGMI) and the rest afterwards (fused.backward(leaf.grad))."""
         from .models.adapter import adapter_apply
         self._set_precision()
         cur = torch.cuda.current_stream()
@@ -142,8 +145,11 @@ class SERSystem(nn.Module):
             t_seq.record_stream(cur)
             a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
             fused = self.head(a_seq, a_mask, t_seq, attn_mask.to(torch.float32))
-            logits, unc, _ = self.classifier(fused, use_openmax=False, return_uncertainty=True)
-        total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)
+            leaf = fused.detach().requires_grad_() if split else fused
+            logits, unc, _ = self.classifier(leaf, use_openmax=False, return_uncertainty=True)
+        total = self.criterion(logits, unc, leaf, self.prototypes.prototypes, labels, use_proto=use_proto)
+        if split:
+            return total, logits, fused, leaf
         return total, logits
 
     def head(self, a_seq, a_mask, t_seq, t_mask):
@@ -174,6 +180,13 @@ class SERSystem(nn.Module):
             logits, unc, anchor = self.classifier(fused, use_openmax=False, return_uncertainty=True)
         total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)
         return total, logits
+
+    def check_persistent_kernels(self):
+        """Raise if a bounded hand-off wait inside the persistent classifier kernels was ever abandoned (sticky word 1 of
+        their scratch areas, csrc/persist.hip): from then on the stack's outputs are not trustworthy."""
+        cache = getattr(self.classifier, "_stack_cache", None)
+        if cache is not None and any(int(sc[1]) != 0 for sc in cache[3]):
+            raise RuntimeError("a hand-off wait inside the persistent classifier kernels was abandoned")
 
     # ---- data parallel -------------------------------------------------------------------------------------------
     def buckets(self):
@@ -289,6 +302,10 @@ class TrainStepper:
         self.g_fb = self.g_b = self.g_opt = None
         self.static = None
         self.loss = None
+        # one captured graph set per input shape (waveform length, token count, batch size): real manifests produce a few
+        # distinct shapes (length buckets, the last partial batch); beyond `max_graphs` a new shape runs eagerly
+        self._graphs = {}
+        self.max_graphs = 8
 
     def _fwd_bwd(self, wave, ids, mask, labels):
         loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto)
@@ -301,9 +318,11 @@ class TrainStepper:
     # ---- split form: the classifier + loss hang off a detached copy of `fused`
     def _fwd_bwd_a(self, wave, ids, mask, labels):
         s = self.sys
-        fused = s.head(*s.encode(wave, ids, mask))
-        leaf = fused.detach().requires_grad_()
-        logits, unc, _ = s.classifier(leaf, use_openmax=False, return_uncertainty=True)
+        s._set_precision()
+        with s._dropout_scope():              # the same precision mode and training-mode dropout as SERSystem.loss
+            fused = s.head(*s.encode(wave, ids, mask))
+            leaf = fused.detach().requires_grad_()
+            logits, unc, _ = s.classifier(leaf, use_openmax=False, return_uncertainty=True)
         loss = s.criterion(logits, unc, leaf, s.prototypes.prototypes, labels, use_proto=self.use_proto)
         with _ops.defer_wgrads():
             loss.backward()
@@ -329,8 +348,20 @@ class TrainStepper:
             self.opt.prepare_step(dev)
             self.opt.launch()
         else:
-            if self.g_fb is None:
+            key = (tuple(wave.shape), tuple(ids.shape))
+            if key not in self._graphs:
+                if len(self._graphs) >= self.max_graphs:      # too many shapes to keep a graph for each: eager step
+                    self.use_graph = False
+                    try:
+                        return self.step(wave, ids, mask, labels)
+                    finally:
+                        self.use_graph = True
+                g_opt = self.g_opt
                 self._capture(wave, ids, mask, labels)
+                if g_opt is not None:
+                    self.g_opt = g_opt                          # the optimizer launch does not depend on the input shape
+                self._graphs[key] = (self.static, self.g_fb, self.g_b, self.loss, self.logits)
+            self.static, self.g_fb, self.g_b, self.loss, self.logits = self._graphs[key]
             for s, t in zip(self.static, (wave, ids, mask, labels)):
                 s.copy_(t, non_blocking=True)
             self.g_fb.replay()
@@ -376,9 +407,10 @@ class TrainStepper:
         else:
             with torch.cuda.graph(self.g_fb):
                 self.loss, self.logits = self._fwd_bwd(*self.static)
-        self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
-            self.opt.launch()
+        if self.g_opt is None or not self._graphs:
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt):
+                self.opt.launch()
 
 
 class PipelinedStepper:
@@ -395,10 +427,15 @@ class PipelinedStepper:
     previously and starts the encoders on `next_batch`.
     """
 
-    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_proto=True):
+    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_proto=True, split_backward=None):
         self.sys, self.opt, self.sched, self.reducer, self.use_proto = system, optimizer, scheduler, reducer, use_proto
         self.enc_stream = torch.cuda.Stream()
-        self.g_enc = self.g_head = self.g_opt = None
+        self.g_enc = self.g_head = self.g_head_b = self.g_opt = None
+        # Data parallel: the head graph is captured in two pieces — A: forward + loss + classifier backward, B: the
+        # backward of fusion / pooling / cross-attention / adapters — and the all-reduce of the classifier bucket (76 MB of
+        # the 100 MB of gradients) is issued between them, so it travels over xGMI while B runs.  Same arithmetic as the
+        # single graph (the two consumers of `fused` add their gradients in the detached leaf).
+        self.split = (reducer is not None and reducer.early) if split_backward is None else bool(split_backward)
         self.loss = None
         self.pending = False
 
@@ -418,9 +455,7 @@ class PipelinedStepper:
             self.enc_cur = [a.clone(), t.clone()]
             for _ in range(2):
                 self.opt.zero_grad(set_to_none=True)
-                loss, _ = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
-                with _ops.defer_wgrads():
-                    loss.backward()
+                self._head_fwd_bwd()
             self.opt.prepare_step(dev)
             self.opt.t -= 1
             if self.opt._plan is None:
@@ -438,16 +473,46 @@ class PipelinedStepper:
             self.enc_next[0].copy_(a)
             self.enc_next[1].copy_(t)
         self.g_head = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_head):
-            loss, logits = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
-            with _ops.defer_wgrads():
-                loss.backward()
-            _ops.wgrad_join()
-            self.loss, self.logits = loss.detach(), logits.detach()
+        if self.split:
+            with torch.cuda.graph(self.g_head):
+                self.loss, self.logits = self._head_a()
+            self.g_head_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_head_b, pool=self.g_head.pool()):
+                self._head_b()
+        else:
+            with torch.cuda.graph(self.g_head):
+                self.loss, self.logits = self._head_fwd_bwd()
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt):
             self.opt.launch()
         self._pick_encoder_stream()
+
+    def _head_a(self):
+        s = self.sys
+        loss, logits, fused, leaf = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels,
+                                                        self.use_proto, split=True)
+        with _ops.defer_wgrads():
+            loss.backward()
+        _ops.wgrad_join()
+        self._fused, self._dfused = fused, leaf.grad
+        return loss.detach(), logits.detach()
+
+    def _head_b(self):
+        with _ops.defer_wgrads():
+            self._fused.backward(self._dfused)
+        _ops.wgrad_join()
+        self._fused = self._dfused = None
+
+    def _head_fwd_bwd(self):
+        if self.split:
+            out = self._head_a()
+            self._head_b()
+            return out
+        loss, logits = self.sys.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
+        with _ops.defer_wgrads():
+            loss.backward()
+        _ops.wgrad_join()
+        return loss.detach(), logits.detach()
 
     def _pick_encoder_stream(self, candidates=6, reps=3):
         """HIP multiplexes streams onto a few hardware queues; two streams that land on the same queue run their
@@ -464,6 +529,8 @@ class PipelinedStepper:
                 with torch.cuda.stream(es):
                     self.g_enc.replay()
                 self.g_head.replay()
+                if self.g_head_b is not None:
+                    self.g_head_b.replay()
                 cur.wait_stream(es)
             e1.record(cur)
             torch.cuda.synchronize()
@@ -498,6 +565,10 @@ class PipelinedStepper:
         self.cur_labels.copy_(self.in_next[3], non_blocking=True)
         self.feed(wave, ids, mask, labels)        # encoders of the NEXT batch: other stream, runs beside the head
         self.g_head.replay()
+        if self.g_head_b is not None:
+            if self.reducer:                      # classifier bucket + prototypes on their way while the rest of backward runs
+                self.reducer.start([self.sys.classifier._flat], [self.sys.prototypes.prototypes])
+            self.g_head_b.replay()
         if self.reducer:
             self.reducer.finish()
         self.opt.prepare_step(dev)
