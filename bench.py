@@ -26,6 +26,7 @@ SR = 16000
 # algorithmic FLOPs per utterance (2 x MAC), SURVEY.md section 8(d), config 2/3 shapes (S_a=199, S_t=32, Base)
 FLOP_FWD_PER_UTT = 63.4e9
 FLOP_TRAIN_FROZEN_PER_UTT = 65.4e9
+FLOP_TRAIN_FULL_PER_UTT = 190.2e9    # BASELINE config 3: 3 x forward for every trained product
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -43,14 +44,14 @@ def hf_configs(stress=False, vocab=250002):
     return wc, xc
 
 
-def build_system(precision, device, num_labels=4, stress=False, vocab=250002):
+def build_system(precision, device, num_labels=4, stress=False, vocab=250002, unfreeze=False):
     import ser_amd  # noqa: F401
     from ser_amd.models import AudioEncoder, TextEncoder
     from ser_amd.system import SERSystem
     wc, xc = hf_configs(stress, vocab)
     torch.manual_seed(0)            # identical random-init replicas on every rank
-    ae = AudioEncoder(hf_config=wc, use_quality_gates=False, use_audio_conditioning=False, precision=precision)
-    te = TextEncoder(hf_config=xc, precision=precision)
+    ae = AudioEncoder(hf_config=wc, use_quality_gates=False, use_audio_conditioning=False, precision=precision, freeze_base=not unfreeze)
+    te = TextEncoder(hf_config=xc, precision=precision, freeze_base=not unfreeze)
     sysm = SERSystem(ae, te, num_labels=num_labels)
     return sysm.to(device), wc, xc
 
@@ -170,6 +171,8 @@ def main():
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds; the timed CPU steps stop early (>= 3 kept) beyond it")
     ap.add_argument("--stress", action="store_true", help="BASELINE config 5 encoder sizes (1024-d, 24 layers)")
+    ap.add_argument("--unfreeze", action="store_true",
+                    help="BASELINE config 3: full fine-tune (encoders unfrozen, reference freeze_base=False); use with --batch 8")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -205,7 +208,7 @@ def main():
         L.lib.ser_debug_set_gemm_lds_pad(int(os.environ["SER_GEMM_LDS_PAD"]))
     if os.environ.get("SER_GEMM_PERSIST"):
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
-    sysm, wc, xc = build_system(args.precision, dev, stress=args.stress)
+    sysm, wc, xc = build_system(args.precision, dev, stress=args.stress, unfreeze=args.unfreeze)
     sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
     sysm.train()
     sample = None
@@ -220,7 +223,7 @@ def main():
     batches = [[t.to(dev) for t in synth_batch(args.batch, args.seconds, args.tokens, xc.vocab_size, sysm.num_labels,
                                                1234 + rank + 1000 * j)] for j in range(4)]
     batch = batches[0]
-    pipeline = use_graph and not args.no_pipeline
+    pipeline = use_graph and not args.no_pipeline and not args.unfreeze     # unfrozen encoders depend on the last update: no overlap across steps
     if pipeline:
         from ser_amd.system import PipelinedStepper
         stepper = PipelinedStepper(sysm, opt, None, reducer)
@@ -261,12 +264,15 @@ def main():
     roof = None
     if rank == 0:
         eager = TrainStepper(sysm, opt, None, None, use_graph=False)
-        L.check(L.lib.ser_prof_gemm_start())
+        prof_start, prof_stop = (L.lib.ser_prof_gemm_f32_start, L.lib.ser_prof_gemm_f32_stop) if args.unfreeze \
+            else (L.lib.ser_prof_gemm_start, L.lib.ser_prof_gemm_stop)
+        L.check(prof_start())
         nprof = 3
         for _ in range(nprof):
             eager.step(*batch)
         ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
-        L.check(L.lib.ser_prof_gemm_stop(C.byref(ms), C.byref(fl), C.byref(n)))
+        prof_stop.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+        L.check(prof_stop(C.byref(ms), C.byref(fl), C.byref(n)))
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, separate --pmc runs; see profiles/): bench.py cannot run the profiler itself
@@ -276,12 +282,15 @@ def main():
                 traffic = round(json.load(fh)["gemm_bf16"]["hbm_bytes_per_launch"])
         except Exception:  # noqa: BLE001
             traffic = None
-        nprod = 3 if args.precision == "bf16x3" else 1
+        nprod = 3 if (args.precision == "bf16x3" or args.unfreeze) else 1
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                     traffic_source="committed rocprofv3 --pmc passes (profiles/pmc_traffic_latest.json), not this run",
                     mfma_pipe_utilisation=round(nprod * achieved / PEAK_BF16_TFLOPS, 4),
-                    kernel="gemm_bf16_nt_kernel + gemm_bf16_pair_kernel (same tile code; the pair form runs layer l of both encoders)", launches_per_step=n.value // nprof,
+                    kernel=("gemm_x3_kernel / gemm_x3_group_kernel / gemm_f32_kernel (csrc/gemm_f32.hip: fp32 operands split to bf16 hi+lo on the fly; "
+                            "forward, dgrad and wgrad products of encoders and head)" if args.unfreeze else
+                            "gemm_bf16_nt_kernel + gemm_bf16_pair_kernel (same tile code; the pair form runs layer l of both encoders)"),
+                    launches_per_step=n.value // nprof,
                     avg_launch_us=round(ms.value * 1e3 / max(1, n.value), 2),
                     algorithmic_gflop_per_step=round(fl.value / nprof / 1e9, 1),
                     mfma_products_per_mac=nprod)
@@ -293,19 +302,24 @@ def main():
         cpu, err, same, spread = (None, None, None, None)
         if sample is not None:
             cpu, err, same, spread = cpu_baseline_and_parity(sample, sysm, wc, xc, args)
-        step_tflops = value * FLOP_TRAIN_FROZEN_PER_UTT / 1e12 if not args.stress and args.seconds == 4.0 and args.tokens == 32 else None
+        per_utt = FLOP_TRAIN_FULL_PER_UTT if args.unfreeze else FLOP_TRAIN_FROZEN_PER_UTT
+        step_tflops = value * per_utt / 1e12 if not args.stress and args.seconds == 4.0 and args.tokens == 32 else None
         out = {
-            "metric": "utterances/sec (train step, %gs@16kHz + %d tok)" % (args.seconds, args.tokens), "value": round(value, 2), "unit": "utt/s",
+            "metric": "utterances/sec (%strain step, %gs@16kHz + %d tok)" % ("full fine-tune " if args.unfreeze else "", args.seconds, args.tokens),
+            "value": round(value, 2), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "RAVDESS-shaped synthetic: %gs@16kHz waveform + %d-token text, batch %d per GPU, "
-                                   "%s frozen (random init), adapters + cross-attention + pooling + "
+                                   "%s %s (random init), adapters + cross-attention + pooling + "
                                    "gated fusion + 35-block OpenMax classifier trained, AdamW"
                                    % (args.seconds, args.tokens, args.batch,
-                                      "Large-sized (1024-d, 24-layer) Wav2Vec2 + XLM-R" if args.stress else "Wav2Vec2-Base + XLM-R-Base"),
+                                      "Large-sized (1024-d, 24-layer) Wav2Vec2 + XLM-R" if args.stress else "Wav2Vec2-Base + XLM-R-Base",
+                                      "trained too (full fine-tune, 397 M parameters)" if args.unfreeze else "frozen"),
                        "global_batch": world * args.batch,
-                       "precision": ("bf16x3: operands split into bf16 hi+lo planes, 3 bf16 MFMA products per multiply, fp32 accumulate"
+                       "precision": ("fp32 tensors, every product = 3 bf16 MFMA products on operands split hi+lo on the fly, fp32 accumulate"
+                                     if args.unfreeze else
+                                     "bf16x3: operands split into bf16 hi+lo planes, 3 bf16 MFMA products per multiply, fp32 accumulate"
                                      if args.precision == "bf16x3" else "bf16: 1 bf16 MFMA product per multiply, fp32 accumulate (fast mode, no 1e-3 parity claim)"),
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
                        "schedule": "frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "

@@ -339,6 +339,35 @@ int ser_dropout(const float* x, long long n, const void* state, unsigned site, f
  * hyper (device) = {lr, 1 - beta1^t, sqrt(1 - beta2^t)}; effective lr = hyper[0] * lr_mult. */
 int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float lr_mult,
               float weight_decay, float beta1, float beta2, float eps, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * fine-tuning path of the encoders (BASELINE config 3: reference freeze_base=False,
+ * src/models/audio_encoder.py:15-17, text_encoder.py:13-15).  Products, LayerNorm and attention
+ * reuse ser_gemm_f32 / ser_linear_* / ser_layernorm_fwd,bwd / ser_xattn_fwd,bwd; these are the rest.
+ * ------------------------------------------------------------------------------------------- */
+/* dx = dy * d/dx[x Phi(x)] from the pre-activation x (hf activations.py GELUActivation). */
+int ser_gelu_bwd(const float* dy, const float* x, long long n, float* dx, void* stream);
+/* GroupNorm with one channel per group = normalisation over time per (clip, channel); x [B][L][C] channels-last
+ * (hf modeling_wav2vec2.py:302-323).  workspace: ser_colnorm_workspace_bytes(B, C). */
+size_t ser_colnorm_workspace_bytes(int B, int C);
+int ser_colnorm_fwd(const float* x, int B, int L, int C, const float* gamma, const float* beta, float eps, float* y,
+                    float* mean, float* rstd, void* workspace, void* stream);
+int ser_colnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int B,
+                    int L, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
+/* Adjoint of the positional conv's window view: dslab[r][c] = sum_j dwin[r - j][j * Cg + c] (hf :326-368). */
+int ser_toeplitz_add(const float* dwin, int rows_win, int K, int Cg, int rows_slab, float* dslab, void* stream);
+/* XLM-R embeddings word[id] + type[0] + pos[pid] and the scatter-add backward; rows whose index equals pad_id leave
+ * that table's gradient untouched (nn.Embedding(padding_idx), hf modeling_xlm_roberta.py:75-121). */
+int ser_embed_fwd(const int64_t* ids, const int64_t* pos, const float* wemb, const float* pemb, const float* temb,
+                  int rows, int D, int vocab, int max_pos, float* e, void* stream);
+int ser_embed_bwd(const float* de, const int64_t* ids, const int64_t* pos, int rows, int D, int vocab, int max_pos,
+                  int pad_id, float* dw, float* dp, float* dt, void* stream);
+/* (x - mean) / sqrt(var + 1e-7) per clip (hf feature_extraction_wav2vec2.py:78-96); stats: B float2 of scratch. */
+int ser_wave_normalize(const float* wave, int B, int T, float* out, void* stats, void* stream);
+
+/* HIP-event timing of every ser_gemm_f32-family launch between start and stop (measurement aid). */
+int ser_prof_gemm_f32_start(void);
+int ser_prof_gemm_f32_stop(double* total_ms, double* total_flops, long long* launches);
+
 /* Measured tile height (64..192 rows) for the BN = 128 encoder GEMMs of shape (rows_total, N, K), recorded by the
  * engines' one-time timing pass; `three_products` selects the table of the interleaved three-product mode.  Speed only. */
 int ser_gemm_tile_hint(long long rows_total, int N, int K, int bm);

@@ -272,6 +272,12 @@ __global__ __launch_bounds__(1024) void wave_stats_kernel(const float* __restric
   }
 }
 
+int ser_launch_wave_stats(const float* wave, int B, int T, void* stats, hipStream_t st) {
+  hipLaunchKernelGGL(wave_stats_kernel, dim3(B), dim3(1024), 0, st, wave, T, (float2*)stats);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // conv0 (1 -> C0 channels, kernel KW, stride ST, no bias) + GroupNorm(C0 groups) + GELU
 // (hf modeling_wav2vec2.py:302-323).  Pass 1 accumulates sum / sum-of-squares per (clip, channel)

@@ -1,0 +1,259 @@
+// Kernels that only the fine-tuning path of the encoders needs (BASELINE config 3: reference freeze_base=False,
+// src/models/audio_encoder.py:15-17, text_encoder.py:13-15).  Its matrix products, LayerNorms and attention reuse the
+// fp32 operators of the trainable head (gemm_f32.hip, head.hip); what is left are the pieces the head does not have:
+//   * erf-GELU backward from the pre-activation                       (hf activations.py GELUActivation)
+//   * GroupNorm(C groups of one channel) over time, channels-last      (hf modeling_wav2vec2.py:302-323)
+//   * overlap-add of the positional conv's window gradients            (hf modeling_wav2vec2.py:326-368)
+//   * XLM-R embedding gather-sum and its scatter-add backward          (hf modeling_xlm_roberta.py:75-121, padding_idx rows get no gradient)
+//   * clip normalisation as a stand-alone op                           (hf feature_extraction_wav2vec2.py:78-96)
+// All HBM-bound, coalesced along the channel / feature axis.
+#include "ser_common.h"
+
+namespace {
+
+static inline unsigned ew_grid(long long n, int per_block = 256) {
+  long long b = (n + per_block - 1) / per_block;
+  return (unsigned)(b < 1 ? 1 : (b > 65535 ? 65535 : b));
+}
+
+// d/dx [x Phi(x)] = Phi(x) + x phi(x)
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long n, float* __restrict__ dx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
+    dx[i] = dy[i] * (cdf + v * pdf);
+  }
+}
+
+// ---- GroupNorm with one channel per group == per-(clip, channel) normalisation over time; x [B][L][C] channels-last.
+// One workgroup = 64 channels of one clip x a slice of the frames; partial sums are combined with atomics into [B][C]
+// double accumulators (zeroed by the caller), so the reduction order varies in the last bits only at double precision.
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int L, int C, int rows_per_block,
+                                                       double* __restrict__ sum, double* __restrict__ sq) {
+  __shared__ double sh[2][4][64];
+  const int b = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int t0 = blockIdx.y * rows_per_block, t1 = min(L, t0 + rows_per_block);
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (int t = t0 + rg; t < t1; t += 4) {
+      const double v = x[((long long)b * L + t) * C + c];
+      s += v;
+      q += v * v;
+    }
+  sh[0][rg][threadIdx.x & 63] = s;
+  sh[1][rg][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    atomicAdd(sum + (long long)b * C + c, (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]));
+    atomicAdd(sq + (long long)b * C + c, (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]));
+  }
+}
+__global__ void colstats_finish_kernel(const double* __restrict__ sum, const double* __restrict__ sq, int n, int L, float eps,
+                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double m = sum[i] / L;
+  double var = sq[i] / L - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ void colnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int L, int C, long long n,
+                                     float* __restrict__ y) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long bc = (i / C / L) * C + c;
+    y[i] = (x[i] - mean[bc]) * rstd[bc] * gamma[c] + beta[c];
+  }
+}
+// backward, pass 1: per (clip, channel) s1 = sum_t dy, s2 = sum_t dy * xhat  (double accumulators, zeroed by the caller)
+__global__ __launch_bounds__(256) void colnorm_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                int L, int C, int rows_per_block, double* __restrict__ s1,
+                                                                double* __restrict__ s2) {
+  __shared__ double sh[2][4][64];
+  const int b = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int t0 = blockIdx.y * rows_per_block, t1 = min(L, t0 + rows_per_block);
+  double a = 0.0, q = 0.0;
+  if (c < C) {
+    const float m = mean[(long long)b * C + c], r = rstd[(long long)b * C + c];
+    for (int t = t0 + rg; t < t1; t += 4) {
+      const long long o = ((long long)b * L + t) * C + c;
+      const double g = dy[o];
+      a += g;
+      q += g * (double)((x[o] - m) * r);
+    }
+  }
+  sh[0][rg][threadIdx.x & 63] = a;
+  sh[1][rg][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    const int l = threadIdx.x & 63;
+    atomicAdd(s1 + (long long)b * C + c, (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]));
+    atomicAdd(s2 + (long long)b * C + c, (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]));
+  }
+}
+// pass 2: dx = gamma * rstd * (dy - s1 / L - xhat * s2 / L)
+__global__ void colnorm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                         const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                         const double* __restrict__ s1, const double* __restrict__ s2, int L, int C, long long n,
+                                         float* __restrict__ dx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long long bc = (i / C / L) * C + c;
+    const float r = rstd[bc], xh = (x[i] - mean[bc]) * r;
+    dx[i] = gamma[c] * r * (dy[i] - (float)(s1[bc] / L) - xh * (float)(s2[bc] / L));
+  }
+}
+// dgamma[c] (+)= sum_b s2[b][c], dbeta[c] (+)= sum_b s1[b][c]
+__global__ void colnorm_bwd_param_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int B, int C, int accumulate,
+                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, q = 0.0;
+  for (int b = 0; b < B; ++b) {
+    a += s1[(long long)b * C + c];
+    q += s2[(long long)b * C + c];
+  }
+  dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)q;
+  dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)a;
+}
+
+// ---- overlap-add: dslab[r][c] = sum_j dwin[r - j][j * Cg + c] over the taps j with 0 <= r - j < rows_win
+// (the adjoint of viewing slab rows t .. t + K - 1 as one window row of K * Cg values)
+__global__ void toeplitz_add_kernel(const float* __restrict__ dwin, int rows_win, int K, int Cg, int rows_slab,
+                                    float* __restrict__ dslab) {
+  const long long n = (long long)rows_slab * Cg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cg), r = (int)(i / Cg);
+    const int j0 = max(0, r - (rows_win - 1)), j1 = min(K - 1, r);
+    float a = 0.f;
+    for (int j = j0; j <= j1; ++j) a += dwin[(long long)(r - j) * K * Cg + (long long)j * Cg + c];
+    dslab[i] = a;
+  }
+}
+
+// ---- XLM-R embeddings: e[row] = word[id] + type[0] + pos[pid]
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ pos, const float* __restrict__ wemb,
+                                 const float* __restrict__ pemb, const float* __restrict__ temb, int rows, int D, int vocab,
+                                 int max_pos, float* __restrict__ e) {
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  long long id = ids[row], p = pos[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+  for (int d = threadIdx.x; d < D; d += blockDim.x)
+    e[(long long)row * D + d] = (wemb[id * D + d] + temb[d]) + pemb[p * D + d];
+}
+// scatter-add; rows whose index is the padding index leave that table untouched (nn.Embedding(padding_idx))
+__global__ void embed_bwd_kernel(const float* __restrict__ de, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos,
+                                 int rows, int D, int vocab, int max_pos, int pad_id, float* __restrict__ dw, float* __restrict__ dp,
+                                 float* __restrict__ dt) {
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  long long id = ids[row], p = pos[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float g = de[(long long)row * D + d];
+    if (id != pad_id) atomicAdd(dw + id * D + d, g);
+    if (p != pad_id) atomicAdd(dp + p * D + d, g);
+    atomicAdd(dt + d, g);
+  }
+}
+
+__global__ void wave_normalize_kernel(const float* __restrict__ wave, const float2* __restrict__ stats, int T, long long n,
+                                      float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float2 s = stats[i / T];
+    out[i] = (wave[i] - s.x) * s.y;
+  }
+}
+
+}  // namespace
+
+int ser_launch_wave_stats(const float* wave, int B, int T, void* stats, hipStream_t st);   // elementwise.hip
+
+extern "C" int ser_gelu_bwd(const float* dy, const float* x, long long n, float* dx, void* stream) {
+  if (n <= 0) return SER_OK;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, x, n, dx);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" size_t ser_colnorm_workspace_bytes(int B, int C) { return (size_t)2 * B * C * sizeof(double) + 256; }
+
+extern "C" int ser_colnorm_fwd(const float* x, int B, int L, int C, const float* gamma, const float* beta, float eps, float* y,
+                               float* mean, float* rstd, void* workspace, void* stream) {
+  SER_REQUIRE(x && y && mean && rstd && workspace && B > 0 && L > 0 && C > 0, "colnorm_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  double* sum = (double*)workspace;
+  double* sq = sum + (size_t)B * C;
+  SER_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)2 * B * C * sizeof(double), st));
+  const int rpb = 512;
+  hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), ceil_div(L, rpb), B), dim3(256), 0, st, x, L, C, rpb, sum, sq);
+  hipLaunchKernelGGL(colstats_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, sum, sq, B * C, L, eps, mean, rstd);
+  const long long n = (long long)B * L * C;
+  hipLaunchKernelGGL(colnorm_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, mean, rstd, gamma, beta, L, C, n, y);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_colnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int B,
+                               int L, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream) {
+  SER_REQUIRE(dy && x && mean && rstd && gamma && workspace && B > 0 && L > 0 && C > 0, "colnorm_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  double* s1 = (double*)workspace;
+  double* s2 = s1 + (size_t)B * C;
+  SER_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)2 * B * C * sizeof(double), st));
+  const int rpb = 512;
+  hipLaunchKernelGGL(colnorm_bwd_stats_kernel, dim3(ceil_div(C, 64), ceil_div(L, rpb), B), dim3(256), 0, st, dy, x, mean, rstd, L, C,
+                     rpb, s1, s2);
+  const long long n = (long long)B * L * C;
+  if (dx) hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, x, mean, rstd, gamma, s1, s2, L, C, n, dx);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(colnorm_bwd_param_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, s1, s2, B, C, accumulate, dgamma, dbeta);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_toeplitz_add(const float* dwin, int rows_win, int K, int Cg, int rows_slab, float* dslab, void* stream) {
+  SER_REQUIRE(dwin && dslab && rows_win > 0 && K > 0 && Cg > 0 && rows_slab > 0, "toeplitz_add: bad argument");
+  hipLaunchKernelGGL(toeplitz_add_kernel, dim3(ew_grid((long long)rows_slab * Cg)), dim3(256), 0, (hipStream_t)stream, dwin, rows_win, K,
+                     Cg, rows_slab, dslab);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+extern "C" int ser_embed_fwd(const int64_t* ids, const int64_t* pos, const float* wemb, const float* pemb, const float* temb,
+                             int rows, int D, int vocab, int max_pos, float* e, void* stream) {
+  SER_REQUIRE(ids && pos && wemb && pemb && temb && e && rows > 0 && D > 0, "embed_fwd: bad argument");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, ids, pos, wemb, pemb, temb, rows, D, vocab,
+                     max_pos, e);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+/* dw [vocab, D], dp [max_pos, D], dt [D] must be zero-filled (or hold the gradients to accumulate into) */
+extern "C" int ser_embed_bwd(const float* de, const int64_t* ids, const int64_t* pos, int rows, int D, int vocab, int max_pos,
+                             int pad_id, float* dw, float* dp, float* dt, void* stream) {
+  SER_REQUIRE(de && ids && pos && dw && dp && dt && rows > 0 && D > 0, "embed_bwd: bad argument");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, de, ids, pos, rows, D, vocab, max_pos, pad_id,
+                     dw, dp, dt);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+/* out[b][t] = (wave[b][t] - mean_b) / sqrt(var_b + 1e-7); stats: B float2 of scratch */
+extern "C" int ser_wave_normalize(const float* wave, int B, int T, float* out, void* stats, void* stream) {
+  SER_REQUIRE(wave && out && stats && B > 0 && T > 0, "wave_normalize: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  SER_TRY(ser_launch_wave_stats(wave, B, T, stats, st));
+  const long long n = (long long)B * T;
+  hipLaunchKernelGGL(wave_normalize_kernel, dim3(ew_grid(n)), dim3(256), 0, st, wave, (const float2*)stats, T, n, out);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}

@@ -12,6 +12,7 @@
 // Tiles are staged through LDS k-major (As[k][m], Bs[k][n]) so the MFMA operand reads
 // (A[m = lane&15][k = lane>>4]) are conflict-free ds_read_b32; global loads are register-prefetched
 // one k-tile ahead, one barrier per k-tile.
+#include <vector>
 #include "ser_common.h"
 
 struct SerGemmF32Args {
@@ -890,7 +891,50 @@ static bool vec_ok(const float* p, long long s_fast, long long s_slow, int exten
   return s_fast == 1 && (s_slow % 4) == 0 && (extent % 4) == 0 && (((uintptr_t)p) & 15) == 0;
 }
 
+// optional per-launch HIP-event timing (bench.py roofline leg of the fine-tuning configuration, where this kernel
+// family carries the encoders' products); off by default
+struct ProfRecF32 { hipEvent_t e0, e1; double flops; };
+static bool g_prof_f32_on = false;
+static std::vector<ProfRecF32> g_prof_f32;
+extern "C" int ser_prof_gemm_f32_start(void) {
+  g_prof_f32.clear();
+  g_prof_f32_on = true;
+  return SER_OK;
+}
+extern "C" int ser_prof_gemm_f32_stop(double* total_ms, double* total_flops, long long* launches) {
+  g_prof_f32_on = false;
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : g_prof_f32) {
+    SER_CHECK_HIP(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    SER_CHECK_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t;
+    fl += r.flops;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (long long)g_prof_f32.size();
+  g_prof_f32.clear();
+  return SER_OK;
+}
+static int launch_gemm_f32_inner(const SerGemmF32Args& gin, hipStream_t st);
+
 int ser_launch_gemm_f32(const SerGemmF32Args& gin, hipStream_t st) {
+  if (!g_prof_f32_on) return launch_gemm_f32_inner(gin, st);
+  ProfRecF32 rec;
+  SER_CHECK_HIP(hipEventCreate(&rec.e0));
+  SER_CHECK_HIP(hipEventCreate(&rec.e1));
+  rec.flops = 2.0 * gin.M * (double)gin.N * gin.K;
+  SER_CHECK_HIP(hipEventRecord(rec.e0, st));
+  const int rc = launch_gemm_f32_inner(gin, st);
+  SER_CHECK_HIP(hipEventRecord(rec.e1, st));
+  g_prof_f32.push_back(rec);
+  return rc;
+}
+
+static int launch_gemm_f32_inner(const SerGemmF32Args& gin, hipStream_t st) {
   SerGemmF32Args g = gin;
   SER_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0, "gemm_f32: empty problem M=%d N=%d K=%d", g.M, g.N, g.K);
   SER_REQUIRE(g.a && g.b && g.c, "gemm_f32: null operand");

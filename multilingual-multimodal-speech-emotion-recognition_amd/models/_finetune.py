@@ -1,0 +1,359 @@
+"""Fine-tuning form of the two encoders — BASELINE config 3: the reference's `freeze_base=False`
+(src/models/audio_encoder.py:15-17, src/models/text_encoder.py:13-15, src/train_two_phase.py:166-172), where every
+Wav2Vec2 / XLM-R parameter receives a gradient.
+
+The frozen path (csrc/encoders.hip) keeps the encoders as packed split-bf16 planes and has no backward.  This path runs
+the same arithmetic in fp32 tensors through the operators of the trainable head — every matrix product is
+`ser_gemm_f32` (fp32 in / out, three bf16 MFMA products per multiply with the operands split on the fly, any strides:
+which makes a Conv1d a GEMM over a strided window view, its input gradient one accumulating GEMM per tap, and its weight
+gradient a GEMM over the same view), LayerNorm / attention are the head's `ser_layernorm_fwd,bwd` / `ser_xattn_fwd,bwd`, and
+csrc/finetune.hip adds the pieces the head never needed (GELU backward, GroupNorm over time, the positional conv's
+overlap-add, embedding gather / scatter-add).  torch is the autograd tape and the view / permute plumbing; the one place
+torch arithmetic is used is the weight-norm of the positional conv's 4.7 M-element weight (g * v / ||v||, a parameter
+transform, hf modeling_wav2vec2.py:326-349).
+
+Semantics: eval-mode HuggingFace forward (no encoder dropout / SpecAugment / LayerDrop), i.e. what the golden gradients
+of tests/golden/{audio,text}_encoder_grads.npz were captured with; `masked_spec_embed` and the XLM-R pooler take no part
+and get no gradient.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib as L
+from .. import _ops as O
+
+_sig = L._sig
+_sig("ser_gelu_bwd", L.i32, L.vp, L.vp, L.i64, L.vp, L.vp)
+_sig("ser_colnorm_workspace_bytes", L.sz, L.i32, L.i32)
+_sig("ser_colnorm_fwd", L.i32, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.f32, L.vp, L.vp, L.vp, L.vp, L.vp)
+_sig("ser_colnorm_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp)
+_sig("ser_toeplitz_add", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
+_sig("ser_embed_fwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
+_sig("ser_embed_bwd", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp)
+_sig("ser_wave_normalize", L.i32, L.vp, L.i32, L.i32, L.vp, L.vp, L.vp)
+
+
+def _gemm(a_ptr, sam, sak, b_ptr, sbk, sbn, M, N, K, c, ldc, bias=None, accumulate=False):
+    """c[M,N] (+)= A . B (+ bias) with element strides (ser_gemm_f32): A[m,k] = a + m*sam + k*sak, B[k,n] = b + k*sbk + n*sbn."""
+    L.check(L.lib.ser_gemm_f32(a_ptr, int(sam), int(sak), b_ptr, int(sbk), int(sbn), int(M), int(N), int(K), L.ptr(bias), L.ACT_NONE, None,
+                               0, c.data_ptr() if isinstance(c, torch.Tensor) else c, int(ldc), 1 if accumulate else 0, L.stream_ptr()),
+            "ser_gemm_f32")
+
+
+def _wgrad_now(dy, x, dW, db):
+    """Weight gradient written before backward returns: the buffers handed back to autograd become the parameters' .grad,
+    so the head's deferred (grouped, end-of-backward) weight-gradient launches must not be used for them."""
+    prev = O._DEFER["active"]
+    O._DEFER["active"] = False
+    try:
+        O.linear_wgrad(dy, x, dW, db)
+    finally:
+        O._DEFER["active"] = prev
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b on contiguous fp32 [M, K]: the head's Linear kernels (forward / dgrad / wgrad with the bias gradient
+    folded in)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_b = b is not None
+        return O.linear_fwd(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = O.linear_dgrad(dy, W) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W)
+        db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_b else None
+        _wgrad_now(dy, x, dW, db)
+        return dx, dW, db
+
+
+def linear(x, W, b=None):
+    shp = x.shape
+    y = _Linear.apply(x.reshape(-1, shp[-1]).contiguous(), W, b)
+    return y.reshape(*shp[:-1], W.shape[0])
+
+
+class _ConvWin(torch.autograd.Function):
+    """Conv1d(C_in -> C_out, kernel k, stride s, no padding, no bias) on channels-last x [B, L, C_in] as GEMMs over the
+    strided window view (row t of clip b = x[b, s t : s t + k, :], k*C_in contiguous values, row stride s*C_in): no im2col
+    copy.  W2 [C_out, k*C_in] holds the taps in (tap, channel) order.  Backward: dW2 accumulates dy^T . windows over the clips;
+    dx is one accumulating GEMM per tap, dx[b, s t + j, :] += dy[b, t, :] . W2[:, j*C_in : (j+1)*C_in] — rows of one tap
+    never collide, taps run one after the other on the stream."""
+
+    @staticmethod
+    def forward(ctx, x, W2, k, s):
+        B, Lin, Cin = x.shape
+        Cout = W2.shape[0]
+        Lout = (Lin - k) // s + 1
+        y = torch.empty(B, Lout, Cout, dtype=torch.float32, device=x.device)
+        for b in range(B):
+            _gemm(x[b].data_ptr(), s * Cin, 1, W2.data_ptr(), 1, k * Cin, Lout, Cout, k * Cin, y[b], Cout)
+        ctx.save_for_backward(x, W2)
+        ctx.k, ctx.s = k, s
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W2 = ctx.saved_tensors
+        k, s = ctx.k, ctx.s
+        B, Lin, Cin = x.shape
+        Cout, Lout = W2.shape[0], dy.shape[1]
+        dy = dy.contiguous()
+        dW2 = torch.empty_like(W2)
+        for b in range(B):      # dW2[n, kk] (+)= sum_t dy[b, t, n] * win[b, t, kk]
+            _gemm(dy[b].data_ptr(), 1, Cout, x[b].data_ptr(), s * Cin, 1, Cout, k * Cin, Lout, dW2, k * Cin, accumulate=b > 0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.zeros_like(x)
+            for b in range(B):
+                for j in range(k):
+                    _gemm(dy[b].data_ptr(), Cout, 1, W2.data_ptr() + 4 * j * Cin, k * Cin, 1, Lout, Cin, Cout,
+                          dx[b].data_ptr() + 4 * j * Cin, s * Cin, accumulate=True)
+        return dx, dW2, None, None
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return O.act_fwd(x, O.ACT_GELU)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib.ser_gelu_bwd(L.ptr(dy), L.ptr(x), x.numel(), L.ptr(dx), L.stream_ptr()), "ser_gelu_bwd")
+        return dx
+
+
+gelu = _Gelu.apply
+
+
+class _LayerNorm(torch.autograd.Function):
+    """LN(x (+ x2)) over the last dim on [rows, D]: the head's kernels (saved: the sum, mean, rstd)."""
+
+    @staticmethod
+    def forward(ctx, x, x2, gamma, beta, eps):
+        y, saved = O.ln_fwd(x.contiguous(), gamma, beta, eps, x2=None if x2 is None else x2.contiguous())
+        ctx.save_for_backward(saved[0], saved[1], saved[2], gamma)
+        ctx.two = x2 is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, gamma = ctx.saved_tensors
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        dx = O.ln_bwd(dy.contiguous(), (z, mean, rstd), gamma, dg, db)
+        return dx, (dx if ctx.two else None), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps, residual=None):
+    shp = x.shape
+    y = _LayerNorm.apply(x.reshape(-1, shp[-1]), None if residual is None else residual.reshape(-1, shp[-1]), gamma, beta, eps)
+    return y.reshape(shp)
+
+
+class _ColNorm(torch.autograd.Function):
+    """GroupNorm(C, C) on channels-last [B, L, C]: per (clip, channel) statistics over time (hf :302-323)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        B, Ln, Cc = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(int(L.lib.ser_colnorm_workspace_bytes(B, Cc)), dtype=torch.uint8, device=x.device)
+        L.check(L.lib.ser_colnorm_fwd(L.ptr(x), B, Ln, Cc, L.ptr(gamma), L.ptr(beta), eps, L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(ws),
+                                      L.stream_ptr()), "ser_colnorm_fwd")
+        ctx.save_for_backward(x, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        B, Ln, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(int(L.lib.ser_colnorm_workspace_bytes(B, Cc)), dtype=torch.uint8, device=x.device)
+        L.check(L.lib.ser_colnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), B, Ln, Cc, L.ptr(dx), L.ptr(dg),
+                                      L.ptr(db), 0, L.ptr(ws), L.stream_ptr()), "ser_colnorm_bwd")
+        return dx, dg, db, None
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d) + key mask) v per head on [B*S, H] operands: the head's attention kernels
+    (hf wav2vec2 :438-463, xlm_roberta :211-250)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, B, S, heads):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, P = O.xattn_fwd(q, k, v, key_mask, B, S, S, heads)
+        ctx.save_for_backward(q, k, v, P)
+        ctx.dims = (B, S, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q, k, v, P = ctx.saved_tensors
+        B, S, heads = ctx.dims
+        dq, dk, dv = O.xattn_bwd(dctx.contiguous(), q, k, v, P, B, S, S, heads)
+        return dq, dk, dv, None, None, None, None
+
+
+class _Toeplitz(torch.autograd.Function):
+    """One group of the positional conv for all clips at once.  slab [B*R + K, Cg]: per clip R = S + K - 1 zero-padded
+    rows, clips back to back (+ K rows of slack), so the window rows of every clip are ONE strided view with row step Cg:
+    out[m] = slab[m : m + K].flatten() . W2^T for m in [0, B*R) — the rows m = b R + t, t >= S, straddle two clips and are
+    never used (their upstream gradient is zero)."""
+
+    @staticmethod
+    def forward(ctx, slab, W2, bias, rows, K):
+        Cg = slab.shape[1]
+        N = W2.shape[0]
+        y = torch.empty(rows, N, dtype=torch.float32, device=slab.device)
+        _gemm(slab.data_ptr(), Cg, 1, W2.data_ptr(), 1, K * Cg, rows, N, K * Cg, y, N, bias=bias)
+        ctx.save_for_backward(slab, W2)
+        ctx.rows, ctx.K = rows, K
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        slab, W2 = ctx.saved_tensors
+        rows, K = ctx.rows, ctx.K
+        Cg, N = slab.shape[1], W2.shape[0]
+        dy = dy.contiguous()
+        dW2 = torch.empty_like(W2)
+        _gemm(dy.data_ptr(), 1, N, slab.data_ptr(), Cg, 1, N, K * Cg, rows, dW2, K * Cg)
+        db = torch.empty(N, dtype=torch.float32, device=dy.device)
+        L.check(L.lib.ser_colsum(L.ptr(dy), rows, N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
+        dslab = None
+        if ctx.needs_input_grad[0]:
+            dwin = O.linear_dgrad(dy, W2)                               # [rows, K*Cg]
+            dslab = torch.empty_like(slab)
+            L.check(L.lib.ser_toeplitz_add(L.ptr(dwin), rows, K, Cg, slab.shape[0], L.ptr(dslab), L.stream_ptr()), "ser_toeplitz_add")
+        return dslab, dW2, db, None, None
+
+
+class _Embed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, pos, wemb, pemb, temb, pad_id):
+        rows, D = ids.numel(), wemb.shape[1]
+        e = torch.empty(rows, D, dtype=torch.float32, device=wemb.device)
+        L.check(L.lib.ser_embed_fwd(L.ptr(ids), L.ptr(pos), L.ptr(wemb), L.ptr(pemb), L.ptr(temb), rows, D, wemb.shape[0], pemb.shape[0],
+                                    L.ptr(e), L.stream_ptr()), "ser_embed_fwd")
+        ctx.save_for_backward(ids, pos)
+        ctx.shapes = (wemb.shape, pemb.shape, temb.shape, pad_id)
+        return e
+
+    @staticmethod
+    def backward(ctx, de):
+        ids, pos = ctx.saved_tensors
+        ws, ps, ts, pad_id = ctx.shapes
+        de = de.contiguous()
+        dw = torch.zeros(ws, dtype=torch.float32, device=de.device)
+        dp = torch.zeros(ps, dtype=torch.float32, device=de.device)
+        dt = torch.zeros(ts, dtype=torch.float32, device=de.device)
+        L.check(L.lib.ser_embed_bwd(L.ptr(de), L.ptr(ids), L.ptr(pos), ids.numel(), ws[1], ws[0], ps[0], pad_id, L.ptr(dw), L.ptr(dp),
+                                    L.ptr(dt), L.stream_ptr()), "ser_embed_bwd")
+        return None, None, dw, dp, dt, None
+
+
+def normalise_waves(wave):
+    """[B, T] raw clips -> zero mean / unit variance per clip (hf feature_extraction_wav2vec2.py:78-96)."""
+    wave = wave.contiguous()
+    B, T = wave.shape
+    out = torch.empty_like(wave)
+    stats = torch.empty(B, 2, dtype=torch.float32, device=wave.device)
+    L.check(L.lib.ser_wave_normalize(L.ptr(wave), B, T, L.ptr(out), L.ptr(stats), L.stream_ptr()), "ser_wave_normalize")
+    return out
+
+
+def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask):
+    """Post-LN block (hf wav2vec2 :591-608 / xlm_roberta :421-463), h [B*S, H]."""
+    g = lambda n: p[prefix + n]
+    q = linear(h, g(names["q"] + ".weight"), g(names["q"] + ".bias"))
+    k = linear(h, g(names["k"] + ".weight"), g(names["k"] + ".bias"))
+    v = linear(h, g(names["v"] + ".weight"), g(names["v"] + ".bias"))
+    ctx = _Attention.apply(q, k, v, key_mask, B, S, heads)
+    a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"))
+    h = layer_norm(a, g(names["ln1"] + ".weight"), g(names["ln1"] + ".bias"), eps, residual=h)
+    f = gelu(linear(h, g(names["f1"] + ".weight"), g(names["f1"] + ".bias")))
+    f = linear(f, g(names["f2"] + ".weight"), g(names["f2"] + ".bias"))
+    return layer_norm(f, g(names["ln2"] + ".weight"), g(names["ln2"] + ".bias"), eps, residual=h)
+
+
+W2V = dict(q="attention.q_proj", k="attention.k_proj", v="attention.v_proj", o="attention.out_proj", ln1="layer_norm",
+           f1="feed_forward.intermediate_dense", f2="feed_forward.output_dense", ln2="final_layer_norm")
+XLMR = dict(q="attention.self.query", k="attention.self.key", v="attention.self.value", o="attention.output.dense",
+            ln1="attention.output.LayerNorm", f1="intermediate.dense", f2="output.dense", ln2="output.LayerNorm")
+
+
+def wav2vec2_forward(model, wave):
+    """Wav2Vec2Model (eval semantics) with gradients: wave [B, T] raw clips of equal length -> last_hidden_state [B, S, H]."""
+    c = model.config
+    assert c.feat_extract_norm == "group" and not c.do_stable_layer_norm and not c.conv_bias, \
+        "only the wav2vec2-base family (group-norm front end, post-LN encoder) is implemented"
+    p = dict(model.named_parameters())
+    eps = c.layer_norm_eps
+    x = normalise_waves(wave.to(torch.float32))
+    B = x.shape[0]
+    h = x[:, :, None]                                                     # channels-last [B, T, 1]
+    for i, (k, s) in enumerate(zip(c.conv_kernel, c.conv_stride)):
+        w = p[f"feature_extractor.conv_layers.{i}.conv.weight"]           # [C_out, C_in, k]
+        W2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)                   # taps in (tap, channel) order; a view op under autograd
+        h = _ConvWin.apply(h.contiguous(), W2.contiguous(), k, s)
+        if i == 0:
+            h = _ColNorm.apply(h, p["feature_extractor.conv_layers.0.layer_norm.weight"],
+                               p["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)
+        h = gelu(h)
+    S = h.shape[1]
+    e = layer_norm(h.reshape(B * S, -1), p["feature_projection.layer_norm.weight"], p["feature_projection.layer_norm.bias"], eps)
+    z = linear(e, p["feature_projection.projection.weight"], p["feature_projection.projection.bias"])       # [B*S, H]
+    H = z.shape[1]
+    # positional conv: weight_norm(dim=2) W = g * v / ||v||_(0,1); grouped conv, padding K/2, last frame dropped when K is even
+    g0 = p["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
+    v0 = p["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
+    Wp = g0 * v0 / torch.sqrt((v0 * v0).sum(dim=(0, 1), keepdim=True))                                      # [H, Cg, K]
+    K, G = c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups
+    Cg, R = H // G, S + K - 1
+    zb = z.reshape(B, S, G, Cg)
+    bp = p["encoder.pos_conv_embed.conv.bias"]
+    outs = []
+    for gi in range(G):
+        slab = torch.nn.functional.pad(zb[:, :, gi, :], (0, 0, K // 2, K - 1 - K // 2))                     # [B, R, Cg] zero rows around each clip
+        slab = torch.cat([slab.reshape(B * R, Cg), slab.new_zeros(K, Cg)], dim=0)
+        W2 = Wp[gi * Cg:(gi + 1) * Cg].permute(0, 2, 1).reshape(Cg, K * Cg).contiguous()
+        y = _Toeplitz.apply(slab.contiguous(), W2, bp[gi * Cg:(gi + 1) * Cg].contiguous(), B * R, K)          # [B*R, Cg], bias added in the GEMM
+        outs.append(y.reshape(B, R, Cg)[:, :S, :])
+    pc = torch.cat(outs, dim=2).reshape(B * S, H)
+    h = layer_norm(gelu(pc), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps, residual=z)   # LN(z + GELU(conv))
+    for i in range(c.num_hidden_layers):
+        h = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None)
+    return h.reshape(B, S, H)
+
+
+def xlmr_forward(model, ids, attn_mask):
+    """XLMRobertaModel (eval semantics) with gradients: ids [B, S] int64, attn_mask [B, S] 1/0 -> last_hidden_state."""
+    c = model.config
+    p = dict(model.named_parameters())
+    B, S = ids.shape
+    pad = c.pad_token_id
+    m = (ids != pad).to(torch.int64)
+    pos = torch.cumsum(m, dim=1) * m + pad                               # hf :142-155 (index arithmetic)
+    e = _Embed.apply(ids.contiguous(), pos.contiguous(), p["embeddings.word_embeddings.weight"], p["embeddings.position_embeddings.weight"],
+                     p["embeddings.token_type_embeddings.weight"], pad)
+    h = layer_norm(e, p["embeddings.LayerNorm.weight"], p["embeddings.LayerNorm.bias"], c.layer_norm_eps)
+    mask = attn_mask.to(torch.float32).contiguous()
+    for i in range(c.num_hidden_layers):
+        h = _transformer_layer(h, p, f"encoder.layer.{i}.", XLMR, B, S, c.num_attention_heads, c.layer_norm_eps, mask)
+    return h.reshape(B, S, -1)

@@ -135,8 +135,9 @@ class AudioEncoder(nn.Module):
 
     def encode(self, wave: torch.Tensor) -> torch.Tensor:
         """[B,T] equal-length raw clips on the device -> [B,S,H] (encoder + adapter)."""
-        if not self.freeze_base:
-            raise NotImplementedError("encoder fine-tuning (freeze_base=False) is not built yet: BASELINE config 3")
+        if not self.freeze_base:       # BASELINE config 3: every Wav2Vec2 parameter is trained (ref :15-17)
+            from ._finetune import wav2vec2_forward
+            return adapter_apply(self, wav2vec2_forward(self.encoder, wave))
         with torch.no_grad():
             seq = self.engine().forward(wave)
         return adapter_apply(self, seq)

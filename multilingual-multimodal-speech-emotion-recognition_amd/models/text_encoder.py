@@ -59,11 +59,13 @@ class TextEncoder(nn.Module):
 
     def forward_ids(self, input_ids: torch.Tensor, attention_mask: torch.Tensor):
         """Pre-tokenised entry: ids [B,S] int64, mask [B,S] -> (seq [B,S,H], mask float)."""
-        if not self.freeze_base:
-            raise NotImplementedError("encoder fine-tuning (freeze_base=False) is not built yet: BASELINE config 3")
         dev = self.adapter[0].weight.device
         ids = input_ids.to(dev)
         mask = attention_mask.to(dev)
+        if not self.freeze_base:       # BASELINE config 3: every XLM-R parameter is trained (ref :13-15)
+            from ._finetune import xlmr_forward
+            seq = xlmr_forward(self.encoder, ids, mask)
+            return adapter_apply(self, seq), mask.to(seq.dtype)
         with torch.no_grad():
             seq = self.engine().forward(ids, mask)
         return adapter_apply(self, seq), mask.to(seq.dtype)

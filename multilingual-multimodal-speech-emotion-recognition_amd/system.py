@@ -87,7 +87,11 @@ class SERSystem(nn.Module):
         stream)."""
         from .models.adapter import adapter_apply
         if not (self.audio_encoder.freeze_base and self.text_encoder.freeze_base):
-            raise NotImplementedError("encoder fine-tuning (freeze_base=False) is not built yet: BASELINE config 3")
+            # BASELINE config 3 (reference freeze_base=False): the fine-tuning form of the encoders, with gradients
+            a_seq = self.audio_encoder.encode(wave.to(torch.float32))
+            t_seq, t_mask = self.text_encoder.forward_ids(ids.to(wave.device), attn_mask.to(wave.device))
+            a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
+            return a_seq, a_mask, t_seq, t_mask
         a_enc, t_enc = self.encode_frozen(wave, ids.to(wave.device), attn_mask.to(wave.device))
         cur = torch.cuda.current_stream()
         if self._side is None:
@@ -215,6 +219,11 @@ class GradReducer:
         self.world = dist.get_world_size(process_group)
         self.system, self.overlap = system, overlap
         self.loose = [p for p in system.prototypes.parameters()]
+        # fine-tuning (BASELINE config 3): the encoders' own parameters get gradients from autograd; they are reduced as
+        # ONE coalesced buffer per encoder in finish()
+        self.coalesced = [[p for p in m.encoder.parameters() if p.requires_grad]
+                          for m in (system.audio_encoder, system.text_encoder) if not getattr(m, "freeze_base", True)] \
+            if hasattr(system, "audio_encoder") else []
         self.cuda = torch.cuda.is_available() and next(system.parameters()).is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.pending = []
@@ -267,6 +276,13 @@ class GradReducer:
         for p in self.loose:
             if p.grad is not None and id(p) not in self._done:
                 self.pending.append((self._reduce(p.grad), p.grad))
+        back = []
+        for group in self.coalesced:
+            live = [p for p in group if p.grad is not None]
+            if live:
+                flat = torch.cat([p.grad.reshape(-1) for p in live])
+                self.pending.append((self._reduce(flat), flat))
+                back.append((flat, live))
         inv = 1.0 / self.world
         if self.cuda:
             from . import _ops as O
@@ -279,6 +295,12 @@ class GradReducer:
             for w, t in self.pending:
                 w.wait()
                 t.mul_(inv)                       # CPU tensors only occur in the gloo unit tests
+        for flat, live in back:                   # scaled means back into the per-parameter gradients
+            off = 0
+            for p in live:
+                n = p.grad.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
         self.pending.clear()
         self._done.clear()
 

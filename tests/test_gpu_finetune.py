@@ -1,0 +1,150 @@
+"""BASELINE config 3 on the GPU: the fine-tuning form of the encoders (reference `freeze_base=False`,
+src/models/audio_encoder.py:15-17, src/models/text_encoder.py:13-15).
+
+* every Wav2Vec2 / XLM-R / adapter parameter gradient against the golden gradients captured from the reference
+  (tests/golden/{audio,text}_encoder_grads.npz: gradient of sum(out * g) on the recorded inputs), forward against the
+  recorded outputs;
+* one whole training step of the assembled system with unfrozen encoders against the CPU oracle with autograd
+  (logits, loss, sampled gradients everywhere from the conv front end to the classifier) and an AdamW update that moves the
+  encoder weights at their group's learning rate."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ser_oracle as O
+from tests.helpers import cfg_of, load_npz, split_fixture, t
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(named, gr, tol=3e-4):
+    assert gr
+    gmax = max(float(g.abs().max()) for g in gr.values())
+    seen = 0
+    for k, g in gr.items():
+        if k not in named:
+            continue
+        p = named[k]
+        if p.grad is None:
+            assert float(g.abs().max()) == 0.0, f"no gradient reached {k}"
+            continue
+        err = float((p.grad.cpu() - g).abs().max())
+        assert err <= tol * float(g.abs().max()) + 3e-6 * gmax, f"{k}: max-abs-err {err:.2e} (max|grad| {float(g.abs().max()):.2e})"
+        seen += 1
+    assert seen > 20
+
+
+def test_audio_encoder_gradients_match_the_reference():
+    import ser_amd  # noqa: F401
+    from transformers import Wav2Vec2Config
+    from ser_amd.models import AudioEncoder
+    sd, _, r = split_fixture(load_npz("audio_encoder.npz"))
+    _, gr, rg = split_fixture(load_npz("audio_encoder_grads.npz"))
+    c = cfg_of(r)
+    wc = Wav2Vec2Config(hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"], intermediate_size=c["ffn"],
+                        conv_dim=list(c["conv_dim"]), conv_kernel=list(c["conv_kernel"]), conv_stride=list(c["conv_stride"]),
+                        num_conv_pos_embeddings=c["pos_kernel"], num_conv_pos_embedding_groups=c["pos_groups"], layer_norm_eps=c["eps"])
+    ae = AudioEncoder(hf_config=wc, adapter_dim=sd["adapter.0.weight"].shape[0], freeze_base=False, use_quality_gates=False,
+                      use_audio_conditioning=False)
+    ae.load_state_dict(sd, strict=True)
+    ae = ae.cuda().eval()
+    assert all(p.requires_grad for p in ae.encoder.parameters())
+    waves = [t(r["wave0"]).cuda(), t(r["wave1"]).cuda()]
+    seq, mask = ae(waves, ["x", "y"])
+    want = t(r["a_seq"])
+    assert seq.shape == want.shape
+    assert (seq.detach().cpu() - want).abs().max().item() < 2e-4
+    (seq * t(rg["g_out"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    _check(dict(ae.named_parameters()), gr)
+    assert ae.encoder.masked_spec_embed.grad is None or float(ae.encoder.masked_spec_embed.grad.abs().max()) == 0.0
+
+
+def test_text_encoder_gradients_match_the_reference():
+    import ser_amd  # noqa: F401
+    from transformers import XLMRobertaConfig
+    from ser_amd.models import TextEncoder
+    sd, _, r = split_fixture(load_npz("text_encoder.npz"))
+    _, gr, rg = split_fixture(load_npz("text_encoder_grads.npz"))
+    c = cfg_of(r)
+    xc = XLMRobertaConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                          intermediate_size=c["ffn"], max_position_embeddings=c["max_pos"], type_vocab_size=1, layer_norm_eps=c["eps"],
+                          pad_token_id=c["pad_id"], bos_token_id=0, eos_token_id=2)
+    te = TextEncoder(hf_config=xc, adapter_dim=sd["adapter.0.weight"].shape[0], freeze_base=False)
+    te.load_state_dict(sd, strict=True)
+    te = te.cuda().eval()
+    seq, mask = te.forward_ids(t(r["input_ids"]).cuda(), t(r["attention_mask"]).cuda())
+    assert (seq.detach().cpu() - t(r["t_seq"])).abs().max().item() < 2e-4
+    (seq * t(rg["g_out"]).cuda()).sum().backward()
+    torch.cuda.synchronize()
+    named = dict(te.named_parameters())
+    _check(named, gr)
+    # nn.Embedding(padding_idx): the pad rows of the word and position tables get no gradient
+    pad = c["pad_id"]
+    assert float(named["encoder.embeddings.word_embeddings.weight"].grad[pad].abs().max()) == 0.0
+    assert float(named["encoder.embeddings.position_embeddings.weight"].grad[pad].abs().max()) == 0.0
+
+
+def test_full_fine_tune_step_matches_the_oracle():
+    import __graft_entry__ as ge
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    import ser_amd  # noqa: F401
+    from ser_amd.models import AudioEncoder, TextEncoder
+    from ser_amd.system import SERSystem, TrainStepper
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
+                        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    ae = AudioEncoder(hf_config=wc, adapter_dim=32, freeze_base=False, use_quality_gates=False, use_audio_conditioning=False)
+    te = TextEncoder(hf_config=xc, adapter_dim=32, freeze_base=False)
+    sysm = SERSystem(ae, te, num_labels=4, shared_dim=64, num_heads=2, proj_dim=64, num_layers=3, base_dim=64).to(dev)
+    sysm.train()
+    sysm.train_dropout = False
+    g = torch.Generator().manual_seed(5)
+    B, T, S = 4, 4000, 9
+    wave = 0.1 * torch.randn(B, T, generator=g)
+    ids = torch.randint(4, 1000, (B, S), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    mask = torch.ones(B, S)
+    ids[1, S - 3:] = 1
+    ids[1, S - 4] = 2
+    mask[1, S - 3:] = 0
+    labels = torch.randint(0, 4, (B,), generator=g)
+    sds = {k: {n: v.detach().cpu().clone() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    leaf = {k: {n: v.clone().requires_grad_(v.dtype.is_floating_point) for n, v in sd.items()} for k, sd in sds.items()}
+    out = O.full_forward(leaf, list(wave), ids, mask, a_cfg, t_cfg, num_layers=3, heads=2, use_openmax=False, training=True)
+    ref_loss = O.train_loss(out["logits"], out["unc"], out["fused"], leaf["prototypes"]["prototypes"], labels, 4)
+    ref_loss.backward()
+
+    opt = sysm.make_optimizer(lr=1e-3)
+    stepper = TrainStepper(sysm, opt, use_graph=False)
+    opt.zero_grad(set_to_none=True)
+    loss, logits = stepper._fwd_bwd(wave.to(dev), ids.to(dev), mask.to(dev), labels.to(dev))
+    torch.cuda.synchronize()
+    assert (logits.cpu() - out["logits"].detach()).abs().max().item() < 1e-3
+    assert torch.equal(logits.argmax(1).cpu(), out["logits"].argmax(1))
+    assert abs(loss.item() - ref_loss.item()) < 1e-4
+    checked = 0
+    for key in ("audio_encoder", "text_encoder", "cross", "classifier"):
+        named = dict(getattr(sysm, key).named_parameters())
+        for n, v in leaf[key].items():
+            if v.grad is None or n not in named or named[n].grad is None:
+                continue
+            denom = max(v.grad.abs().max().item(), 1e-6)
+            rel = (named[n].grad.cpu() - v.grad).abs().max().item() / denom
+            assert rel < 2e-2 or (named[n].grad.cpu() - v.grad).abs().max().item() < 1e-7, f"{key}.{n}: gradient differs from the oracle (rel {rel:.3e})"
+            checked += 1
+    assert checked > 150
+    w = sysm.audio_encoder.encoder.encoder.layers[0].attention.q_proj.weight
+    c0 = sysm.audio_encoder.encoder.feature_extractor.conv_layers[0].conv.weight
+    before, before_c0 = w.detach().clone(), c0.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    moved = (w.detach() - before).abs().max().item()
+    assert 0.0 < moved <= 1.01e-4 + 1e-6, f"encoder weights move by lr x 0.1 per AdamW step, got {moved}"
+    assert (c0.detach() - before_c0).abs().max().item() > 0.0, "the conv front end is trained too"
