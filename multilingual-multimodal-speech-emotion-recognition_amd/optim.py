@@ -125,7 +125,72 @@ class FlatAdamW:
                     st[f"g{gi}.l{li}"] = dict(m=m.clone(), v=v.clone())
         return dict(t=self.t, base_lr=self.base_lr, lr_factor=self.lr_factor, state=st)
 
-    def load_state_dict(self, sd):
+    # ---- torch.optim.AdamW format (what the reference's checkpoints hold, ref train.py:258) ---------------------------
+    def _moments_of(self, p):
+        """(m, v) views of parameter p inside this optimizer's state (allocating it when absent)."""
+        if self._plan is None:
+            self._build_plan()
+        b, i = find_bucket(p)
+        if b is not None:
+            b.ensure()
+            m, v = self._mv(id(b), b.flat)
+            s = b.offsets[i]
+            return m[s:s + p.numel()].view(p.shape), v[s:s + p.numel()].view(p.shape)
+        return self._mv(id(p), p.data)
+
+    def load_torch_state_dict(self, sd, order, params_by_name):
+        """sd: torch.optim.AdamW.state_dict(); order: [(module key, name)] per optimizer index (SERSystem.torch_param_order
+        of the checkpoint); params_by_name: {(module key, name): parameter} of this system.  Entries of parameters this
+        system does not hold are ignored."""
+        steps = []
+        for idx, st in sd["state"].items():
+            key = order[int(idx)]
+            p = params_by_name.get(key)
+            if p is None or not p.requires_grad:
+                continue
+            m, v = self._moments_of(p)
+            m.copy_(st["exp_avg"].to(m.device))
+            v.copy_(st["exp_avg_sq"].to(v.device))
+            steps.append(int(float(st["step"])))
+        self.t = max(steps) if steps else 0
+        g0 = sd["param_groups"][2]                       # the `cross` group runs at the base learning rate (multiplier 1)
+        self.base_lr = float(g0.get("initial_lr", g0["lr"]))
+        if "initial_lr" in g0 and g0["initial_lr"] > 0:
+            self.lr_factor = float(g0["lr"]) / float(g0["initial_lr"])
+
+    def torch_state_dict(self, order, params_by_name):
+        """This optimizer's state as a torch.optim.AdamW state dict over the parameters in `order`."""
+        index = {k: i for i, k in enumerate(order)}
+        state = {}
+        for key, p in params_by_name.items():
+            if key not in index or not p.requires_grad:
+                continue
+            b, _ = find_bucket(p)
+            if (id(b) if b is not None else id(p)) not in self._state:
+                continue
+            m, v = self._moments_of(p)
+            state[index[key]] = dict(step=torch.tensor(float(self.t)), exp_avg=m.detach().clone(), exp_avg_sq=v.detach().clone())
+        groups, pos = [], 0
+        for g, names in zip(self.groups, self._group_sizes(order)):
+            lr = self.base_lr * self.lr_factor * g["lr_mult"]
+            groups.append(dict(lr=lr, initial_lr=self.base_lr * g["lr_mult"], betas=self.betas, eps=self.eps, weight_decay=g["weight_decay"],
+                               amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                               decoupled_weight_decay=True, params=list(range(pos, pos + names))))
+            pos += names
+        return dict(state=state, param_groups=groups)
+
+    def _group_sizes(self, order):
+        from .system import SERSystem
+        sizes = []
+        for key, prefix in SERSystem.OPT_GROUPS:
+            sizes.append(sum(1 for k, n in order if k == key and n.startswith(prefix)
+                             and (prefix or key != "classifier")))
+        return sizes
+
+    def load_state_dict(self, sd, order=None, params_by_name=None):
+        if "param_groups" in sd:                              # torch.optim.AdamW format (a reference checkpoint)
+            assert order is not None and params_by_name is not None, "a torch-format optimizer state needs the parameter order"
+            return self.load_torch_state_dict(sd, order, params_by_name)
         self.t, self.base_lr, self.lr_factor = sd["t"], sd["base_lr"], sd["lr_factor"]
         if self._plan is None:
             self._build_plan()
@@ -165,5 +230,9 @@ class WarmupCosine:
         return dict(last_epoch=self.last_epoch, total=self.total, W=self.W)
 
     def load_state_dict(self, sd):
-        self.last_epoch, self.total, self.W = sd["last_epoch"], sd["total"], sd["W"]
+        """Own format, or torch's LambdaLR state dict (a reference checkpoint: only the step counter carries over; the
+        schedule's length comes from this run's arguments, as in the reference where the lambda is rebuilt from args)."""
+        self.last_epoch = sd["last_epoch"]
+        if "total" in sd:
+            self.total, self.W = sd["total"], sd["W"]
         self.opt.lr_factor = self.factor(self.last_epoch)

@@ -61,9 +61,44 @@ class SERSystem(nn.Module):
     def checkpoint_dict(self):
         return {k: getattr(self, k).state_dict() for k in self.CKPT_KEYS}
 
-    def load_checkpoint_dict(self, ck):
+    # parameters of the reference's default AudioEncoder() (quality gates / audio conditioning on, ref audio_encoder.py:25-52)
+    # that a module built with the gates off does not have
+    GATE_PREFIXES = ("quality_gates.", "quality_fusion.", "audio_conditioning.", "conditioning_fusion.", "combined_fusion.")
+
+    def load_checkpoint_dict(self, ck, log=None):
+        """Load the eight module entries of a checkpoint in the reference's layout (ref train.py:249-262), written by
+        this package or by the reference itself.  Strict, with one explicit exception: a reference checkpoint carries the
+        gate / conditioning parameters of its default AudioEncoder(); when this system's audio encoder was built without
+        them, exactly those keys (GATE_PREFIXES) are skipped and reported."""
         for k in self.CKPT_KEYS:
-            getattr(self, k).load_state_dict(ck[k])
+            mod, sd = getattr(self, k), ck[k]
+            if k == "audio_encoder":
+                own = set(mod.state_dict().keys())
+                skipped = [n for n in sd if n not in own and n.startswith(self.GATE_PREFIXES)]
+                if skipped:
+                    sd = {n: v for n, v in sd.items() if n not in skipped}
+                    (log or print)(f"load_checkpoint_dict: audio encoder built without quality gates / conditioning; "
+                                   f"skipping {len(skipped)} checkpoint entries ({skipped[0]} ...)")
+            mod.load_state_dict(sd)
+
+    # ---- optimizer state interchange with torch.optim.AdamW (the reference's optimizer, ref train.py:72-83) --------------
+    OPT_GROUPS = (("audio_encoder", ""), ("text_encoder", ""), ("cross", ""), ("pool_a", ""), ("pool_t", ""), ("fusion", ""),
+                  ("classifier", "deep_classifier."), ("classifier", "anchor_clustering."), ("classifier", "uncertainty_head."),
+                  ("prototypes", ""))
+    BUFFER_KEYS = ("weibull_alpha", "weibull_beta", "weibull_tau", "activation_vectors")
+
+    def torch_param_order(self, ck=None):
+        """[(module key, parameter name)] in the index order of the reference's AdamW: its ten groups in order, inside a
+        group the registration order of the parameters, which is the order of the parameter keys of the module's state
+        dict.  With `ck` the order is read from the checkpoint's own state dicts (so parameters this build does not
+        hold, e.g. the gate modules, keep their indices); without it, from this system's modules."""
+        order = []
+        for key, prefix in self.OPT_GROUPS:
+            names = list(ck[key].keys()) if ck is not None else [n for n, _ in getattr(self, key).named_parameters()]
+            for n in names:
+                if n.startswith(prefix) and not any(n.endswith(b) for b in self.BUFFER_KEYS):
+                    order.append((key, n))
+        return order
 
     def make_optimizer(self, lr=1e-4):
         """The ten AdamW parameter groups of ref train.py:72-83."""

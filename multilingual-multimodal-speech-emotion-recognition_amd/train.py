@@ -6,7 +6,7 @@ checkpoint layout (:249-262), on the HIP hot path.
 
 Additions (all optional): --num_labels, --audio_model / --text_model (HF names or local directories),
 --precision {bf16x3,bf16}, --synthetic N (seeded synthetic clips instead of manifests), --graph
-(hipGraph-captured steps, one graph per input shape), --seed, --no_bucketing.
+(hipGraph-captured steps, one graph per input shape), --seed, --no_bucketing, --unfreeze_encoders (BASELINE config 3).
 
 Multi-GPU: launch with torch.distributed.run, one process per GPU.  `ShardedBucketBatchSampler` gives every rank the
 SAME number of batches per epoch (the tail is padded by wrapping around), a rank decodes only its own batches, the
@@ -66,6 +66,8 @@ def build_parser():
     p.add_argument('--graph', action='store_true')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--no_bucketing', action='store_true', help='plain shuffled batches instead of length-bucketed ones')
+    p.add_argument('--unfreeze_encoders', action='store_true',
+                   help='BASELINE config 3: full fine-tune, every Wav2Vec2 / XLM-R parameter trained (reference freeze_base=False)')
     return p
 
 
@@ -123,8 +125,9 @@ class HipEngine:
         from ser_amd.system import GradReducer, SERSystem, TrainStepper
         torch.manual_seed(args.seed)               # identical initial replicas on every rank
         self.args, self.device, self.rank = args, device, rank
-        ae = AudioEncoder(args.audio_model, use_quality_gates=False, use_audio_conditioning=False, precision=args.precision)
-        self.te = TextEncoder(args.text_model, precision=args.precision)
+        frozen = not args.unfreeze_encoders
+        ae = AudioEncoder(args.audio_model, use_quality_gates=False, use_audio_conditioning=False, precision=args.precision, freeze_base=frozen)
+        self.te = TextEncoder(args.text_model, precision=args.precision, freeze_base=frozen)
         self.sys = SERSystem(ae, self.te, num_labels=args.num_labels).to(device)
         self.sys.dropout_seed += rank              # every data-parallel rank draws its own dropout masks
         self.opt = self.sys.make_optimizer(lr=args.lr)
@@ -136,7 +139,8 @@ class HipEngine:
         if args.resume_from and os.path.exists(args.resume_from):
             ck = torch.load(args.resume_from, map_location=device, weights_only=False)
             self.sys.load_checkpoint_dict(ck)
-            self.opt.load_state_dict(ck['optimizer'])
+            by_name = {(k, n): p for k in self.sys.CKPT_KEYS for n, p in getattr(self.sys, k).named_parameters()}
+            self.opt.load_state_dict(ck['optimizer'], order=self.sys.torch_param_order(ck), params_by_name=by_name)
             self.sched.load_state_dict(ck['scheduler'])
             self.start_epoch = ck['epoch'] + 1
             print(f"Resuming from epoch {self.start_epoch}")

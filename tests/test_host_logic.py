@@ -182,3 +182,62 @@ def test_bench_contract_pieces_without_a_gpu():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
                            capture_output=True, text=True, timeout=600)
         assert r.returncode != 0 and "no CPU fallback" in r.stderr and not r.stdout.strip()
+
+
+def test_reference_checkpoint_round_trip(tmp_path):
+    """A checkpoint written by the REFERENCE's modules + torch AdamW / LambdaLR (tests/golden/ref_checkpoint_small.pt, made by
+    make_checkpoint_fixture.py; it also carries the gate parameters of the reference's default AudioEncoder()) loads into
+    this build: module weights, AdamW moments by parameter name despite the shifted indices, step count, scheduler; and
+    the optimizer state exported back in torch's format loads into a torch.optim.AdamW over the same grouping."""
+    import os
+    import torch
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    import ser_amd  # noqa: F401
+    from ser_amd.models import AudioEncoder, TextEncoder
+    from ser_amd.optim import WarmupCosine
+    from ser_amd.system import SERSystem
+    ck = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ref_checkpoint_small.pt"), map_location="cpu", weights_only=False)
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
+                        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    ae = AudioEncoder(hf_config=wc, adapter_dim=32, use_quality_gates=False, use_audio_conditioning=False)
+    te = TextEncoder(hf_config=xc, adapter_dim=32)
+    sysm = SERSystem(ae, te, num_labels=4, shared_dim=64, num_heads=2, proj_dim=64, num_layers=3, base_dim=64)
+    msgs = []
+    sysm.load_checkpoint_dict(ck, log=msgs.append)
+    assert len(msgs) == 1 and "skipping 14 checkpoint entries" in msgs[0]
+    for key in sysm.CKPT_KEYS:                                   # every entry this build holds equals the checkpoint's
+        own = getattr(sysm, key).state_dict()
+        for n, v in own.items():
+            assert torch.equal(v, ck[key][n]), f"{key}.{n}"
+    # gates-on construction takes the same checkpoint strictly
+    ae2 = AudioEncoder(hf_config=wc, adapter_dim=32)
+    ae2.load_state_dict(ck["audio_encoder"], strict=True)
+
+    opt = sysm.make_optimizer(lr=1e-3)
+    sched = WarmupCosine(opt, 10, 0.0)
+    by_name = {(k, n): p for k in sysm.CKPT_KEYS for n, p in getattr(sysm, k).named_parameters()}
+    order = sysm.torch_param_order(ck)
+    opt.load_state_dict(ck["optimizer"], order=order, params_by_name=by_name)
+    sched.load_state_dict(ck["scheduler"])
+    assert opt.t == 2 and sched.last_epoch == 2 and abs(opt.base_lr - 1e-3) < 1e-12
+    assert abs(opt.lr_factor - sched.factor(2)) < 1e-6
+    for name, want in ck["_probe"].items():
+        key, n = name.split(".", 1)
+        m, v = opt._moments_of(by_name[(key, n)])
+        assert torch.allclose(m, want["exp_avg"]) and torch.allclose(v, want["exp_avg_sq"]), name
+        assert float(m.abs().max()) > 0
+    # export in torch's format and load it into a torch AdamW built over this system with the reference's grouping
+    own_order = sysm.torch_param_order()
+    exported = opt.torch_state_dict(own_order, by_name)
+    c = sysm.classifier
+    topt = torch.optim.AdamW([{'params': sysm.audio_encoder.parameters()}, {'params': sysm.text_encoder.parameters()},
+                              {'params': sysm.cross.parameters()}, {'params': sysm.pool_a.parameters()},
+                              {'params': sysm.pool_t.parameters()}, {'params': sysm.fusion.parameters()},
+                              {'params': c.deep_classifier.parameters()}, {'params': c.anchor_clustering.parameters()},
+                              {'params': c.uncertainty_head.parameters()}, {'params': sysm.prototypes.parameters()}], lr=1e-3)
+    topt.load_state_dict(exported)
+    q = sysm.cross.q_a.weight
+    assert torch.allclose(topt.state[q]["exp_avg"], ck["_probe"]["cross.q_a.weight"]["exp_avg"])
+    assert float(topt.state[q]["step"]) == 2.0
