@@ -210,6 +210,9 @@ def main():
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
     sysm, wc, xc = build_system(args.precision, dev, stress=args.stress, unfreeze=args.unfreeze)
     sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
+    if args.unfreeze:                              # the encoders' own training-mode noise, as the reference's .train() gives it
+        for m in (sysm.audio_encoder, sysm.text_encoder):
+            m.encoder_train_noise, m.noise_seed = True, rank
     sysm.train()
     sample = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -329,7 +332,8 @@ def main():
                                              ("classifier bucket (76 of 100 MB) all-reduced over RCCL beside the backward of fusion / pooling / "
                                               "cross-attention / adapters (head graph captured in two pieces), the rest before AdamW"
                                               if getattr(stepper, "split", False) else "all buckets reduced after backward (no overlap)")),
-                       "head_dropout": "training mode (77 nn.Dropout sites active; frozen encoders in eval semantics)"},
+                       "head_dropout": ("training mode (77 nn.Dropout sites of the head + the encoders' HF dropout sites, LayerDrop and SpecAugment)"
+                                        if args.unfreeze else "training mode (77 nn.Dropout sites active; frozen encoders in eval semantics)")},
             "roofline": roof, "cpu_baseline": cpu,
             "logit_max_abs_err_vs_cpu_oracle": err, "class_indices_equal": same,
             "parity_on": "initial weights, before the first optimizer step", "oracle_logit_spread_across_clips": spread,

@@ -195,19 +195,20 @@ class _Attention(torch.autograd.Function):
     (hf wav2vec2 :438-463, xlm_roberta :211-250)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_mask, B, S, heads):
+    def forward(ctx, q, k, v, key_mask, B, S, heads, drop, site):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out, P = O.xattn_fwd(q, k, v, key_mask, B, S, S, heads)
-        ctx.save_for_backward(q, k, v, P)
-        ctx.dims = (B, S, heads)
+        out, P = O.xattn_fwd(q, k, v, key_mask, B, S, S, heads, drop, site)
+        ctx.P = P                                     # the softmax output, or (softmax, dropped) under dropout
+        ctx.save_for_backward(q, k, v)
+        ctx.dims = (B, S, heads, drop, site)
         return out
 
     @staticmethod
     def backward(ctx, dctx):
-        q, k, v, P = ctx.saved_tensors
-        B, S, heads = ctx.dims
-        dq, dk, dv = O.xattn_bwd(dctx.contiguous(), q, k, v, P, B, S, S, heads)
-        return dq, dk, dv, None, None, None, None
+        q, k, v = ctx.saved_tensors
+        B, S, heads, drop, site = ctx.dims
+        dq, dk, dv = O.xattn_bwd(dctx.contiguous(), q, k, v, ctx.P, B, S, S, heads, drop, site)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 class _Toeplitz(torch.autograd.Function):
@@ -268,6 +269,86 @@ class _Embed(torch.autograd.Function):
         return None, None, dw, dp, dt, None
 
 
+# ---- training-mode noise of the encoders themselves (reference: `.train()` on both encoders, src/train.py:124) ----------
+# HF hidden / attention / activation dropout, LayerDrop and SpecAugment.  Off unless the owning module sets
+# `encoder_train_noise` AND a dropout scope is active (SERSystem.loss in training mode): parity with the golden vectors is
+# defined without it.  Dropout masks come from the head's counter-based generator (state word advanced once per step);
+# LayerDrop decisions and SpecAugment spans are host draws, as in HF (`torch.rand([])` / numpy), from a generator owned by
+# the encoder.  Site ids: SITE0 + 500 * encoder + 8 * layer + {0 attention probabilities, 1 hidden after attention,
+# 2 activation, 3 hidden after FFN}; + 400 feature projection, + 401 encoder input, + 402 embeddings.
+SITE0 = 1000
+
+
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, state, p, site):
+        ctx.key = (state, p, site)
+        y = x.clone()
+        O.dropout_(y, (state, p), site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        state, p, site = ctx.key
+        dx = dy.clone()
+        O.dropout_(dx, (state, p), site)
+        return dx, None, None, None
+
+
+class Noise:
+    """What one forward of one encoder draws.  `plan()` fixes the host decisions (LayerDrop, SpecAugment) for a batch."""
+
+    def __init__(self, cfg, enc_index, seed=0):
+        import numpy as np
+        self.enc = enc_index
+        self.rng = np.random.default_rng(seed + 7 * enc_index)
+        g = lambda n, d=0.0: float(getattr(cfg, n, d) or 0.0)
+        if enc_index == 0:       # Wav2Vec2Config
+            self.p_hidden, self.p_attn, self.p_act = g("hidden_dropout"), g("attention_dropout"), g("activation_dropout")
+            self.p_featproj, self.layerdrop = g("feat_proj_dropout"), g("layerdrop")
+            self.mask_prob, self.mask_len, self.mask_min = g("mask_time_prob"), int(getattr(cfg, "mask_time_length", 10)), int(getattr(cfg, "mask_time_min_masks", 2))
+            self.spec = bool(getattr(cfg, "apply_spec_augment", True)) and self.mask_prob > 0
+        else:                    # XLMRobertaConfig
+            self.p_hidden, self.p_attn, self.p_act = g("hidden_dropout_prob"), g("attention_probs_dropout_prob"), 0.0
+            self.p_featproj, self.layerdrop, self.spec = 0.0, 0.0, False
+        self.skip, self.spec_mask = set(), None
+
+    def site(self, layer, k):
+        return SITE0 + 500 * self.enc + 8 * layer + k
+
+    def plan(self, n_layers, B, S):
+        """Host draws for this batch: layers to skip (hf wav2vec2 :700-703) and SpecAugment rows (one batch-1 call per clip,
+        as the reference's per-utterance loop makes them: hf :1293-1302 with _compute_mask_indices :101-218)."""
+        self.skip = {l for l in range(n_layers) if self.layerdrop > 0 and self.rng.random() < self.layerdrop}
+        self.spec_mask = None
+        if self.spec and S >= self.mask_len:
+            import numpy as np
+            m = np.zeros((B, S), dtype=bool)
+            for b in range(B):
+                eps = self.rng.random()
+                n = max(int(self.mask_prob * S / self.mask_len + eps), self.mask_min)
+                if n * self.mask_len > S:
+                    n = S // self.mask_len
+                n = min(n, max(S - (self.mask_len - 1), 0))
+                if n == 0:
+                    continue
+                starts = self.rng.choice(np.arange(S - (self.mask_len - 1)), n, replace=False)
+                for st in starts:
+                    m[b, st:st + self.mask_len] = True
+            self.spec_mask = m
+        return self
+
+
+def _drop(x, noise, p, site):
+    """Dropout site of an encoder: identity unless the encoder's noise is on and a dropout scope is active."""
+    if noise is None or p <= 0.0:
+        return x
+    d = O.dropout_ctx(p)
+    if d is None:
+        return x
+    return _Dropout.apply(x.contiguous(), d[0], d[1], site)
+
+
 def normalise_waves(wave):
     """[B, T] raw clips -> zero mean / unit variance per clip (hf feature_extraction_wav2vec2.py:78-96)."""
     wave = wave.contiguous()
@@ -278,17 +359,25 @@ def normalise_waves(wave):
     return out
 
 
-def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask):
-    """Post-LN block (hf wav2vec2 :591-608 / xlm_roberta :421-463), h [B*S, H]."""
+def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask, noise=None, layer=0):
+    """Post-LN block (hf wav2vec2 :591-608 / xlm_roberta :421-463), h [B*S, H].  With `noise`: attention-probability,
+    hidden (after the attention output and after the FFN output) and activation dropout, as the HF modules place them."""
     g = lambda n: p[prefix + n]
     q = linear(h, g(names["q"] + ".weight"), g(names["q"] + ".bias"))
     k = linear(h, g(names["k"] + ".weight"), g(names["k"] + ".bias"))
     v = linear(h, g(names["v"] + ".weight"), g(names["v"] + ".bias"))
-    ctx = _Attention.apply(q, k, v, key_mask, B, S, heads)
+    adrop = O.dropout_ctx(noise.p_attn) if noise is not None else None
+    ctx = _Attention.apply(q, k, v, key_mask, B, S, heads, adrop, noise.site(layer, 0) if noise is not None else 0)
     a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"))
+    if noise is not None:
+        a = _drop(a, noise, noise.p_hidden, noise.site(layer, 1))
     h = layer_norm(a, g(names["ln1"] + ".weight"), g(names["ln1"] + ".bias"), eps, residual=h)
     f = gelu(linear(h, g(names["f1"] + ".weight"), g(names["f1"] + ".bias")))
+    if noise is not None:
+        f = _drop(f, noise, noise.p_act, noise.site(layer, 2))
     f = linear(f, g(names["f2"] + ".weight"), g(names["f2"] + ".bias"))
+    if noise is not None:
+        f = _drop(f, noise, noise.p_hidden, noise.site(layer, 3))
     return layer_norm(f, g(names["ln2"] + ".weight"), g(names["ln2"] + ".bias"), eps, residual=h)
 
 
@@ -298,8 +387,9 @@ XLMR = dict(q="attention.self.query", k="attention.self.key", v="attention.self.
             ln1="attention.output.LayerNorm", f1="intermediate.dense", f2="output.dense", ln2="output.LayerNorm")
 
 
-def wav2vec2_forward(model, wave):
-    """Wav2Vec2Model (eval semantics) with gradients: wave [B, T] raw clips of equal length -> last_hidden_state [B, S, H]."""
+def wav2vec2_forward(model, wave, noise=None):
+    """Wav2Vec2Model with gradients: wave [B, T] raw clips of equal length -> last_hidden_state [B, S, H].  noise=None: eval
+    semantics; a planned `Noise`: HF training-mode dropout sites, LayerDrop and SpecAugment."""
     c = model.config
     assert c.feat_extract_norm == "group" and not c.do_stable_layer_norm and not c.conv_bias, \
         "only the wav2vec2-base family (group-norm front end, post-LN encoder) is implemented"
@@ -320,6 +410,12 @@ def wav2vec2_forward(model, wave):
     e = layer_norm(h.reshape(B * S, -1), p["feature_projection.layer_norm.weight"], p["feature_projection.layer_norm.bias"], eps)
     z = linear(e, p["feature_projection.projection.weight"], p["feature_projection.projection.bias"])       # [B*S, H]
     H = z.shape[1]
+    if noise is not None:
+        noise.plan(c.num_hidden_layers, B, S)
+        z = _drop(z, noise, noise.p_featproj, SITE0 + 400)
+        if noise.spec_mask is not None:               # SpecAugment (hf :1293-1302): masked frames <- masked_spec_embed (a select, no arithmetic)
+            mk = torch.from_numpy(noise.spec_mask.reshape(B * S)).to(z.device)
+            z = torch.where(mk[:, None], p["masked_spec_embed"][None, :].to(z.dtype), z)
     # positional conv: weight_norm(dim=2) W = g * v / ||v||_(0,1); grouped conv, padding K/2, last frame dropped when K is even
     g0 = p["encoder.pos_conv_embed.conv.parametrizations.weight.original0"]
     v0 = p["encoder.pos_conv_embed.conv.parametrizations.weight.original1"]
@@ -337,13 +433,17 @@ def wav2vec2_forward(model, wave):
         outs.append(y.reshape(B, R, Cg)[:, :S, :])
     pc = torch.cat(outs, dim=2).reshape(B * S, H)
     h = layer_norm(gelu(pc), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps, residual=z)   # LN(z + GELU(conv))
+    if noise is not None:
+        h = _drop(h, noise, noise.p_hidden, SITE0 + 401)
     for i in range(c.num_hidden_layers):
-        h = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None)
+        if noise is not None and i in noise.skip:     # LayerDrop (hf :700-703)
+            continue
+        h = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i)
     return h.reshape(B, S, H)
 
 
-def xlmr_forward(model, ids, attn_mask):
-    """XLMRobertaModel (eval semantics) with gradients: ids [B, S] int64, attn_mask [B, S] 1/0 -> last_hidden_state."""
+def xlmr_forward(model, ids, attn_mask, noise=None):
+    """XLMRobertaModel with gradients: ids [B, S] int64, attn_mask [B, S] 1/0 -> last_hidden_state (noise: as above)."""
     c = model.config
     p = dict(model.named_parameters())
     B, S = ids.shape
@@ -353,7 +453,10 @@ def xlmr_forward(model, ids, attn_mask):
     e = _Embed.apply(ids.contiguous(), pos.contiguous(), p["embeddings.word_embeddings.weight"], p["embeddings.position_embeddings.weight"],
                      p["embeddings.token_type_embeddings.weight"], pad)
     h = layer_norm(e, p["embeddings.LayerNorm.weight"], p["embeddings.LayerNorm.bias"], c.layer_norm_eps)
+    if noise is not None:
+        noise.plan(c.num_hidden_layers, B, S)
+        h = _drop(h, noise, noise.p_hidden, SITE0 + 500 + 402)
     mask = attn_mask.to(torch.float32).contiguous()
     for i in range(c.num_hidden_layers):
-        h = _transformer_layer(h, p, f"encoder.layer.{i}.", XLMR, B, S, c.num_attention_heads, c.layer_norm_eps, mask)
+        h = _transformer_layer(h, p, f"encoder.layer.{i}.", XLMR, B, S, c.num_attention_heads, c.layer_norm_eps, mask, noise, i)
     return h.reshape(B, S, -1)

@@ -63,8 +63,13 @@ class TextEncoder(nn.Module):
         ids = input_ids.to(dev)
         mask = attention_mask.to(dev)
         if not self.freeze_base:       # BASELINE config 3: every XLM-R parameter is trained (ref :13-15)
-            from ._finetune import xlmr_forward
-            seq = xlmr_forward(self.encoder, ids, mask)
+            from ._finetune import Noise, xlmr_forward
+            noise = None
+            if self.training and getattr(self, "encoder_train_noise", False):
+                if getattr(self, "_noise", None) is None:
+                    self._noise = Noise(self.encoder.config, 1, seed=getattr(self, "noise_seed", 0))
+                noise = self._noise
+            seq = xlmr_forward(self.encoder, ids, mask, noise)
             return adapter_apply(self, seq), mask.to(seq.dtype)
         with torch.no_grad():
             seq = self.engine().forward(ids, mask)

@@ -68,6 +68,9 @@ def build_parser():
     p.add_argument('--no_bucketing', action='store_true', help='plain shuffled batches instead of length-bucketed ones')
     p.add_argument('--unfreeze_encoders', action='store_true',
                    help='BASELINE config 3: full fine-tune, every Wav2Vec2 / XLM-R parameter trained (reference freeze_base=False)')
+    p.add_argument('--no_encoder_noise', action='store_true',
+                   help='with --unfreeze_encoders: leave out the encoders\' own training-mode noise (HF dropout sites, LayerDrop, '
+                        'SpecAugment), which is on by default as in the reference (.train() on both encoders, src/train.py:124)')
     return p
 
 
@@ -130,6 +133,9 @@ class HipEngine:
         self.te = TextEncoder(args.text_model, precision=args.precision, freeze_base=frozen)
         self.sys = SERSystem(ae, self.te, num_labels=args.num_labels).to(device)
         self.sys.dropout_seed += rank              # every data-parallel rank draws its own dropout masks
+        if args.unfreeze_encoders and not args.no_encoder_noise:
+            for m in (ae, self.te):
+                m.encoder_train_noise, m.noise_seed = True, args.seed * 64 + rank
         self.opt = self.sys.make_optimizer(lr=args.lr)
         self.sched = WarmupCosine(self.opt, steps_per_epoch * args.epochs, args.warmup_ratio)
         self.reducer = GradReducer(self.sys) if world > 1 else None

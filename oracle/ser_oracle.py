@@ -178,19 +178,48 @@ def wav2vec2_pos_conv_weight(sd: SD) -> Tensor:
     return g * v / nrm
 
 
+class EncoderNoise:
+    """Training-mode noise of one encoder for one step (the reference calls .train() on both encoders, ref train.py:124):
+    HF's dropout sites with the build's mask generator (state = the step's generator state; site ids as in
+    models/_finetune.py: 1000 + 500 * encoder + 8 * layer + {0 attention probabilities, 1 hidden after attention,
+    2 activation, 3 hidden after FFN}, + 400 feature projection, + 401 encoder input, + 402 embeddings), the layers LayerDrop
+    skips (hf wav2vec2 :700-703) and the SpecAugment rows (hf :1293-1302) as given sets / masks."""
+
+    def __init__(self, state: int, enc: int, p_hidden=0.1, p_attn=0.1, p_act=0.1, p_featproj=0.0, skip=(), spec_mask=None):
+        self.state, self.enc = int(state), int(enc)
+        self.p_hidden, self.p_attn, self.p_act, self.p_featproj = p_hidden, p_attn, p_act, p_featproj
+        self.skip, self.spec_mask = set(skip), spec_mask
+
+    def site(self, layer, k):
+        return 1000 + 500 * self.enc + 8 * layer + k
+
+    def drop(self, x: Tensor, p: float, site: int) -> Tensor:
+        return x if p <= 0.0 else x * dropout_mult(self.state, site, tuple(x.shape), p)
+
+
 def transformer_layer_postln(h: Tensor, p: SD, heads: int, eps: float,
-                             names: Dict[str, str], key_bias: Optional[Tensor]) -> Tensor:
+                             names: Dict[str, str], key_bias: Optional[Tensor],
+                             noise: Optional["EncoderNoise"] = None, layer: int = 0) -> Tensor:
     """Post-LN block shared by Wav2Vec2 (hf :591-608) and XLM-R (hf xlm_roberta :421-463)."""
     D = h.shape[-1]
     scale = (D // heads) ** -0.5
     q = linear(h, p[names["q"] + ".weight"], p[names["q"] + ".bias"])
     k = linear(h, p[names["k"] + ".weight"], p[names["k"] + ".bias"])
     v = linear(h, p[names["v"] + ".weight"], p[names["v"] + ".bias"])
-    ctx = mha_core(q, k, v, heads, scale, key_bias)
+    pm = None
+    if noise is not None and noise.p_attn > 0:
+        pm = dropout_mult(noise.state, noise.site(layer, 0), (h.shape[0], heads, h.shape[1], h.shape[1]), noise.p_attn)
+    ctx = mha_core(q, k, v, heads, scale, key_bias, pm)
     a = linear(ctx, p[names["o"] + ".weight"], p[names["o"] + ".bias"])
+    if noise is not None:
+        a = noise.drop(a, noise.p_hidden, noise.site(layer, 1))
     h = layer_norm(h + a, p[names["ln1"] + ".weight"], p[names["ln1"] + ".bias"], eps)
     f = gelu(linear(h, p[names["f1"] + ".weight"], p[names["f1"] + ".bias"]))
+    if noise is not None:
+        f = noise.drop(f, noise.p_act, noise.site(layer, 2))
     f = linear(f, p[names["f2"] + ".weight"], p[names["f2"] + ".bias"])
+    if noise is not None:
+        f = noise.drop(f, noise.p_hidden, noise.site(layer, 3))
     return layer_norm(h + f, p[names["ln2"] + ".weight"], p[names["ln2"] + ".bias"], eps)
 
 
@@ -203,13 +232,18 @@ XLMR_NAMES = dict(q="attention.self.query", k="attention.self.key", v="attention
                   f1="intermediate.dense", f2="output.dense", ln2="output.LayerNorm")
 
 
-def wav2vec2_forward(sd: SD, x: Tensor, cfg) -> Tensor:
-    """Wav2Vec2Model.forward in eval mode.  x [B,T] already normalised.  -> [B,S,H]."""
+def wav2vec2_forward(sd: SD, x: Tensor, cfg, noise: Optional["EncoderNoise"] = None) -> Tensor:
+    """Wav2Vec2Model.forward (eval mode; with `noise`, the training-mode sites).  x [B,T] already normalised.  -> [B,S,H]."""
     eps = cfg["eps"]
     feats = wav2vec2_features(sd, x, cfg)
     e = layer_norm(feats, sd["feature_projection.layer_norm.weight"],
                    sd["feature_projection.layer_norm.bias"], eps)
     z = linear(e, sd["feature_projection.projection.weight"], sd["feature_projection.projection.bias"])
+    if noise is not None:
+        z = noise.drop(z, noise.p_featproj, 1000 + 400)
+        if noise.spec_mask is not None:
+            mk = torch.as_tensor(noise.spec_mask, dtype=torch.bool)
+            z = torch.where(mk[:, :, None], sd["masked_spec_embed"][None, None, :], z)
     # positional conv embedding, hf :351-368, :689-692
     W = wav2vec2_pos_conv_weight(sd)
     K = cfg["pos_kernel"]
@@ -219,8 +253,12 @@ def wav2vec2_forward(sd: SD, x: Tensor, cfg) -> Tensor:
         pc = pc[:, :, :-1]
     h = z + gelu(pc).transpose(1, 2)
     h = layer_norm(h, sd["encoder.layer_norm.weight"], sd["encoder.layer_norm.bias"], eps)
+    if noise is not None:
+        h = noise.drop(h, noise.p_hidden, 1000 + 401)
     for i in range(cfg["layers"]):
-        h = transformer_layer_postln(h, sub(sd, f"encoder.layers.{i}."), cfg["heads"], eps, W2V_NAMES, None)
+        if noise is not None and i in noise.skip:
+            continue
+        h = transformer_layer_postln(h, sub(sd, f"encoder.layers.{i}."), cfg["heads"], eps, W2V_NAMES, None, noise, i)
     return h
 
 
@@ -277,8 +315,8 @@ def xlmr_position_ids(ids: Tensor, pad_id: int) -> Tensor:
     return (torch.cumsum(m, dim=1) * m).long() + pad_id
 
 
-def xlmr_forward(sd: SD, ids: Tensor, attn_mask: Tensor, cfg) -> Tensor:
-    """XLMRobertaModel.forward (eval).  ids [B,S] int64, attn_mask [B,S] 1/0."""
+def xlmr_forward(sd: SD, ids: Tensor, attn_mask: Tensor, cfg, noise: Optional["EncoderNoise"] = None) -> Tensor:
+    """XLMRobertaModel.forward (eval; with `noise`, the training-mode dropout sites).  ids [B,S] int64, attn_mask [B,S] 1/0."""
     eps = cfg["eps"]
     pos = xlmr_position_ids(ids, cfg["pad_id"])
     # nn.Embedding(padding_idx=pad) for words and positions (hf modeling_xlm_roberta.py:75-95): same values, and the pad
@@ -287,10 +325,12 @@ def xlmr_forward(sd: SD, ids: Tensor, attn_mask: Tensor, cfg) -> Tensor:
          + sd["embeddings.token_type_embeddings.weight"][0]
          + F.embedding(pos, sd["embeddings.position_embeddings.weight"], padding_idx=cfg["pad_id"]))
     h = layer_norm(e, sd["embeddings.LayerNorm.weight"], sd["embeddings.LayerNorm.bias"], eps)
+    if noise is not None:
+        h = noise.drop(h, noise.p_hidden, 1000 + 500 + 402)
     key_bias = torch.zeros(attn_mask.shape, dtype=torch.float32)
     key_bias = key_bias.masked_fill(attn_mask == 0, float("-inf"))
     for i in range(cfg["layers"]):
-        h = transformer_layer_postln(h, sub(sd, f"encoder.layer.{i}."), cfg["heads"], eps, XLMR_NAMES, key_bias)
+        h = transformer_layer_postln(h, sub(sd, f"encoder.layer.{i}."), cfg["heads"], eps, XLMR_NAMES, key_bias, noise, i)
     return h
 
 

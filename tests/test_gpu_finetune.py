@@ -148,3 +148,77 @@ def test_full_fine_tune_step_matches_the_oracle():
     moved = (w.detach() - before).abs().max().item()
     assert 0.0 < moved <= 1.01e-4 + 1e-6, f"encoder weights move by lr x 0.1 per AdamW step, got {moved}"
     assert (c0.detach() - before_c0).abs().max().item() > 0.0, "the conv front end is trained too"
+
+
+def test_encoder_training_noise_matches_the_oracle_with_the_same_draws():
+    """The encoders' own training-mode noise (reference: .train() on both encoders, src/train.py:124): HF's hidden /
+    attention / activation dropout sites, LayerDrop and SpecAugment in the fine-tuning path, against the oracle applying
+    the same masks (the build's generator, restated in the oracle), the same skipped layers and the same masked frames:
+    outputs and every parameter gradient."""
+    import ser_amd  # noqa: F401
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    from ser_amd import _ops as OP
+    from ser_amd.models import AudioEncoder, TextEncoder
+    from ser_amd.models._finetune import Noise
+    import __graft_entry__ as ge
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
+                        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, layerdrop=0.3, mask_time_prob=0.3,
+                        mask_time_length=2, mask_time_min_masks=2)
+    xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    ae = AudioEncoder(hf_config=wc, adapter_dim=32, freeze_base=False, use_quality_gates=False, use_audio_conditioning=False).to(dev).train()
+    te = TextEncoder(hf_config=xc, adapter_dim=32, freeze_base=False).to(dev).train()
+    ae.encoder_train_noise = te.encoder_train_noise = True
+    ae.noise_seed = 5                                  # a seed whose first draws skip a layer (asserted below)
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    g = torch.Generator().manual_seed(3)
+    B, T, S = 3, 4000, 9
+    wave = 0.1 * torch.randn(B, T, generator=g)
+    ids = torch.randint(4, 1000, (B, S), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    mask = torch.ones(B, S)
+    ga, gt = torch.randn(B, 12, 128, generator=g), torch.randn(B, S, 128, generator=g)
+    state = torch.full((1,), 777, dtype=torch.int64, device=dev)
+    with OP.dropout_scope(state):
+        a_seq = ae.encode(wave.to(dev))
+        t_seq, _ = te.forward_ids(ids.to(dev), mask.to(dev))
+    assert a_seq.shape == (B, 12, 128)
+    ((a_seq * ga.to(dev)).sum() + (t_seq * gt.to(dev)).sum()).backward()
+    torch.cuda.synchronize()
+    na, nt = ae._noise, te._noise
+    assert na.spec_mask is not None and na.spec_mask.any() and (na.p_hidden, na.p_attn, na.p_act) == (0.1, 0.1, 0.1)
+
+    sda = {n: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for n, v in ae.state_dict().items()}
+    sdt = {n: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for n, v in te.state_dict().items()}
+    noa = O.EncoderNoise(777, 0, na.p_hidden, na.p_attn, na.p_act, na.p_featproj, na.skip, na.spec_mask)
+    not_ = O.EncoderNoise(777, 1, nt.p_hidden, nt.p_attn, 0.0, 0.0)
+    x = torch.stack([O.normalise_waveform(w) for w in wave])
+    ra = O.adapter(O.wav2vec2_forward(O.sub(sda, "encoder."), x, a_cfg, noa), O.sub(sda, "adapter."))
+    rt = O.adapter(O.xlmr_forward(O.sub(sdt, "encoder."), ids, mask, t_cfg, not_), O.sub(sdt, "adapter."))
+    ((ra * ga).sum() + (rt * gt).sum()).backward()
+    clean = O.adapter(O.wav2vec2_forward(O.sub(sda, "encoder."), x, a_cfg), O.sub(sda, "adapter."))
+    assert (clean - ra).abs().max().item() > 0.1, "the noise must change the output"
+    assert (a_seq.detach().cpu() - ra.detach()).abs().max().item() < 5e-4
+    assert (t_seq.detach().cpu() - rt.detach()).abs().max().item() < 5e-4
+    for mod, sd in ((ae, sda), (te, sdt)):
+        named = dict(mod.named_parameters())
+        gmax = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+        n_checked = 0
+        for n, v in sd.items():
+            if v.grad is None or n not in named:
+                continue
+            got = named[n].grad
+            if got is None:
+                assert float(v.grad.abs().max()) == 0.0, n
+                continue
+            err = float((got.cpu() - v.grad).abs().max())
+            assert err <= 2e-3 * float(v.grad.abs().max()) + 1e-5 * gmax, f"{n}: {err:.2e} vs max {float(v.grad.abs().max()):.2e}"
+            n_checked += 1
+        assert n_checked > 30
+    if na.skip:                                         # a skipped layer's parameters get no gradient
+        l = sorted(na.skip)[0]
+        gq = ae.encoder.encoder.layers[l].attention.q_proj.weight.grad
+        assert gq is None or float(gq.abs().max()) == 0.0
+    assert float(ae.encoder.masked_spec_embed.grad.abs().max()) > 0.0, "SpecAugment frames feed gradients to masked_spec_embed"
