@@ -219,7 +219,8 @@ def main():
         sample = parity_sample(sysm, xc, args, dev)      # on the initial weights, before any optimizer step
     opt = sysm.make_optimizer(lr=1e-4)
     reducer = GradReducer(sysm) if world > 1 else None
-    use_graph = not args.no_graph
+    # LayerDrop changes which kernels run from step to step (a host decision, as in HF): the fine-tune configuration steps eagerly
+    use_graph = not args.no_graph and not args.unfreeze
     split = None if "SER_SPLIT_BACKWARD" not in os.environ else os.environ["SER_SPLIT_BACKWARD"] == "1"
     stepper = TrainStepper(sysm, opt, None, reducer, use_graph=use_graph, split_backward=split)
     # four distinct device-resident batches, visited round-robin: nothing can be reused from one step to the next

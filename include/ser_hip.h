@@ -364,6 +364,14 @@ int ser_embed_bwd(const float* de, const int64_t* ids, const int64_t* pos, int r
 /* (x - mean) / sqrt(var + 1e-7) per clip (hf feature_extraction_wav2vec2.py:78-96); stats: B float2 of scratch. */
 int ser_wave_normalize(const float* wave, int B, int T, float* out, void* stats, void* stream);
 
+/* Eval-side consumers of the logits (ref src/eval.py:192-206, src/utils.py:11-14): z = logits / temperature,
+ * probs = softmax(z), pred = first arg-max, energy = -logsumexp(z); any output may be NULL.  C <= 64. */
+int ser_eval_consumers(const float* logits, int B, int C, float temperature, float* probs, int64_t* pred, float* energy,
+                       void* stream);
+/* --calibrate grid search (ref src/eval.py:49-67): ece[g] = mean_n |max softmax(logits_n / temps[g]) - [argmax_n == label_n]|. */
+int ser_temperature_grid(const float* logits, const int64_t* labels, int N, int C, const float* temps, int G, float* ece,
+                         void* stream);
+
 /* HIP-event timing of every ser_gemm_f32-family launch between start and stop (measurement aid). */
 int ser_prof_gemm_f32_start(void);
 int ser_prof_gemm_f32_stop(double* total_ms, double* total_flops, long long* launches);

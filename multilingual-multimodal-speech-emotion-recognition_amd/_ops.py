@@ -452,3 +452,29 @@ def adamw_multi_(segments, hyper, b1, b2, eps):
 def adamw_(p, g, m, v, hyper, lr_mult, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8):
     L.check(L.lib.ser_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(hyper), lr_mult, weight_decay, beta1,
                             beta2, eps, L.stream_ptr()), "ser_adamw")
+
+
+# ---- eval-side consumers (csrc/evalops.hip) --------------------------------------------------------------------------------
+L._sig("ser_eval_consumers", L.i32, L.vp, L.i32, L.i32, L.f32, L.vp, L.vp, L.vp, L.vp)
+L._sig("ser_temperature_grid", L.i32, L.vp, L.vp, L.i32, L.i32, L.vp, L.i32, L.vp, L.vp)
+
+
+def eval_consumers(logits, temperature=1.0):
+    """logits [B, C] -> (probs = softmax(logits / T), pred int64 [B], energy = -logsumexp(logits / T))  (ref eval.py:192-206)."""
+    logits = _c(logits)
+    B, Cc = logits.shape
+    probs = torch.empty_like(logits)
+    pred = torch.empty(B, dtype=torch.int64, device=logits.device)
+    energy = empty(B, like=logits)
+    L.check(L.lib.ser_eval_consumers(L.ptr(logits), B, Cc, float(temperature), L.ptr(probs), L.ptr(pred), L.ptr(energy), L.stream_ptr()),
+            "ser_eval_consumers")
+    return probs, pred, energy
+
+
+def temperature_grid(logits, labels, temps):
+    """ece[g] of the reference's one-bin |confidence - accuracy| proxy for every temperature of the grid (ref eval.py:49-67)."""
+    logits, labels, temps = _c(logits), _c(labels.to(torch.int64)), _c(temps.to(torch.float32))
+    ece = empty(temps.numel(), like=logits)
+    L.check(L.lib.ser_temperature_grid(L.ptr(logits), L.ptr(labels), logits.shape[0], logits.shape[1], L.ptr(temps), temps.numel(),
+                                       L.ptr(ece), L.stream_ptr()), "ser_temperature_grid")
+    return ece

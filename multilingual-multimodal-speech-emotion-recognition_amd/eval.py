@@ -35,15 +35,24 @@ def tta_variants(audio, num_augs=5):
 
 
 def find_optimal_temperature(val_logits, val_labels):
-    """grid search over logspace(-1, 2, 100) of the reference's one-bin |confidence - accuracy| proxy (:49-67)."""
+    """grid search over logspace(-1, 2, 100) of the reference's one-bin |confidence - accuracy| proxy (:49-67): the 100
+    objectives in one launch (`ser_temperature_grid`), then the first strict minimum, as the reference's loop picks it."""
+    from ser_amd import _ops as O
+    temps = torch.logspace(-1, 2, 100, device=val_logits.device)
+    ece = O.temperature_grid(val_logits, val_labels, temps).cpu()
     best_t, best = 1.0, float('inf')
-    for temp in torch.logspace(-1, 2, 100, device=val_logits.device):
-        probs = torch.softmax(val_logits / temp, dim=1)
-        conf, preds = probs.max(dim=1)
-        ece = torch.mean(torch.abs(conf - (preds == val_labels).float()))
-        if ece < best:
-            best, best_t = ece, temp.item()
+    for t_, e in zip(temps.cpu().tolist(), ece.tolist()):
+        if e < best:
+            best, best_t = e, t_
     return best_t
+
+
+def O_axpby(x, acc, a):
+    """acc (+)= a * x on the device (ser_axpby)."""
+    from ser_amd import _ops as O
+    if acc is None:
+        acc = torch.zeros_like(x)
+    return O.axpby(x.contiguous(), acc, a, 1.0)
 
 
 def logits_for(sysm, audio_list, text_list, use_openmax):
@@ -63,7 +72,7 @@ def main(argv=None):
     p.add_argument('--val_manifest', type=str)
     p.add_argument('--audio_model', type=str, default='facebook/wav2vec2-base')
     p.add_argument('--text_model', type=str, default='xlm-roberta-base')
-    p.add_argument('--precision', choices=['bf16', 'bf16x3'], default='bf16')
+    p.add_argument('--precision', choices=['bf16x3', 'bf16'], default='bf16x3')
     args = p.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("the HIP hot path needs an MI355X; there is no CPU fallback")
@@ -91,17 +100,20 @@ def main(argv=None):
     with torch.no_grad():
         for audio_list, text_list, labels in DataLoader(SERDataset(args.manifest), batch_size=args.batch_size,
                                                         collate_fn=collate_fn):
-            if args.use_tta:   # variant-major batches: every variant of the batch is one batched forward
-                variants = [tta_variants(a, args.num_tta) for a in audio_list]
-                lg = torch.stack([logits_for(sysm, [v[k] for v in variants], text_list, True)
-                                  for k in range(len(variants[0]))]).mean(dim=0)
+            if args.use_tta:   # variant-major batches: every variant of the batch is one batched forward; the mean over
+                variants = [tta_variants(a, args.num_tta) for a in audio_list]            # variants is an axpby chain on the device
+                nv = len(variants[0])
+                lg = None
+                for k in range(nv):
+                    lk = logits_for(sysm, [v[k] for v in variants], text_list, True)
+                    lg = O_axpby(lk, lg, 1.0 / nv)
             else:
                 lg = logits_for(sysm, audio_list, text_list, True)
-            if args.calibrate:
-                lg = lg / temp
-            probs.append(torch.softmax(lg, dim=1).cpu())
-            preds.append(lg.argmax(dim=1).cpu())
-            energies.append(energy_score(lg).cpu())
+            from ser_amd import _ops as O
+            pr, pd, en = O.eval_consumers(lg, temp if args.calibrate else 1.0)     # /T, softmax, arg-max, -logsumexp in one launch
+            probs.append(pr.cpu())
+            preds.append(pd.cpu())
+            energies.append(en.cpu())
             gold.append(labels)
     preds, gold = torch.cat(preds), torch.cat(gold)
     energies, probs = torch.cat(energies).numpy(), torch.cat(probs).numpy()

@@ -139,7 +139,9 @@ class HipEngine:
         self.opt = self.sys.make_optimizer(lr=args.lr)
         self.sched = WarmupCosine(self.opt, steps_per_epoch * args.epochs, args.warmup_ratio)
         self.reducer = GradReducer(self.sys) if world > 1 else None
-        self.stepper = TrainStepper(self.sys, self.opt, self.sched, self.reducer, use_graph=args.graph, use_proto=args.proto_weight > 0)
+        noisy = args.unfreeze_encoders and not args.no_encoder_noise     # LayerDrop / SpecAugment are per-step host decisions: no graph
+        self.stepper = TrainStepper(self.sys, self.opt, self.sched, self.reducer, use_graph=args.graph and not noisy,
+                                    use_proto=args.proto_weight > 0)
         self.aug = AugmentRng(args.seed, rank) if args.augment else None
         self.start_epoch = 0
         if args.resume_from and os.path.exists(args.resume_from):

@@ -318,3 +318,42 @@ def test_backward_token_gemms_in_one_product_mode(M, M_, N, K):
     # 3-product default: fp32-equivalent
     dx3 = OP.linear_dgrad(dy, W)
     assert (dx3.double() - full).abs().max().item() < 2e-4 * full.abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,T", [(5, 4, 1.0), (33, 6, 0.37), (1, 2, 12.5), (64, 64, 2.0)])
+def test_eval_consumers_against_torch(B, C, T):
+    """/T, softmax, arg-max and the energy score -logsumexp (ref eval.py:192-206, utils.py:11-14) in one launch."""
+    import ser_amd  # noqa: F401
+    from ser_amd import _ops as OP
+    g = torch.Generator().manual_seed(B * 100 + C)
+    lg = 3.0 * torch.randn(B, C, generator=g)
+    lg[0, :2] = lg[0].max() + 1.0                       # a tie: torch.argmax returns the first index
+    pr, pd, en = OP.eval_consumers(lg.cuda(), T)
+    z = lg.double() / T
+    assert (pr.cpu().double() - torch.softmax(z, 1)).abs().max().item() < 2e-6
+    assert torch.equal(pd.cpu(), z.argmax(1))
+    assert (en.cpu().double() + torch.logsumexp(z, 1)).abs().max().item() < 1e-5
+
+
+def test_temperature_grid_against_the_reference_loop():
+    """--calibrate (ref eval.py:49-67): the 100 objectives of the grid in one launch, and the temperature the reference's
+    loop would pick (first strict minimum)."""
+    import ser_amd  # noqa: F401
+    from ser_amd import _ops as OP
+    from ser_amd import eval as E
+    g = torch.Generator().manual_seed(8)
+    N, C = 300, 6
+    lg = 2.5 * torch.randn(N, C, generator=g)
+    y = torch.where(torch.rand(N, generator=g) < 0.6, lg.argmax(1), torch.randint(0, C, (N,), generator=g))
+    temps = torch.logspace(-1, 2, 100)
+    ece = OP.temperature_grid(lg.cuda(), y.cuda(), temps.cuda()).cpu()
+    want, best_t, best = [], 1.0, float("inf")
+    for t_ in temps:
+        probs = torch.softmax(lg / t_, dim=1)
+        conf, preds = probs.max(dim=1)
+        e = torch.mean(torch.abs(conf - (preds == y).float()))
+        want.append(float(e))
+        if e < best:
+            best, best_t = e, t_.item()
+    assert (ece - torch.tensor(want)).abs().max().item() < 2e-6
+    assert abs(E.find_optimal_temperature(lg.cuda(), y.cuda()) - best_t) < 1e-6
