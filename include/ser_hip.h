@@ -346,13 +346,14 @@ int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const f
  * ------------------------------------------------------------------------------------------- */
 /* dx = dy * d/dx[x Phi(x)] from the pre-activation x (hf activations.py GELUActivation). */
 int ser_gelu_bwd(const float* dy, const float* x, long long n, float* dx, void* stream);
-/* GroupNorm with one channel per group = normalisation over time per (clip, channel); x [B][L][C] channels-last
- * (hf modeling_wav2vec2.py:302-323).  workspace: ser_colnorm_workspace_bytes(B, C). */
+/* GroupNorm with one channel per group = normalisation over time per (clip, channel); x [B][Ls][C] channels-last, the
+ * first L of a clip's Ls rows are its frames, the rest padding (written as zeros) (hf modeling_wav2vec2.py:302-323).
+ * workspace: ser_colnorm_workspace_bytes(B, C). */
 size_t ser_colnorm_workspace_bytes(int B, int C);
-int ser_colnorm_fwd(const float* x, int B, int L, int C, const float* gamma, const float* beta, float eps, float* y,
+int ser_colnorm_fwd(const float* x, int B, int L, int Ls, int C, const float* gamma, const float* beta, float eps, float* y,
                     float* mean, float* rstd, void* workspace, void* stream);
 int ser_colnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int B,
-                    int L, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
+                    int L, int Ls, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
 /* Adjoint of the positional conv's window view: dslab[r][c] = sum_j dwin[r - j][j * Cg + c] (hf :326-368). */
 int ser_toeplitz_add(const float* dwin, int rows_win, int K, int Cg, int rows_slab, float* dslab, void* stream);
 /* XLM-R embeddings word[id] + type[0] + pos[pid] and the scatter-add backward; rows whose index equals pad_id leave

@@ -29,7 +29,8 @@ __global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __res
 // ---- GroupNorm with one channel per group == per-(clip, channel) normalisation over time; x [B][L][C] channels-last.
 // One workgroup = 64 channels of one clip x a slice of the frames; partial sums are combined with atomics into [B][C]
 // double accumulators (zeroed by the caller), so the reduction order varies in the last bits only at double precision.
-__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int L, int C, int rows_per_block,
+// Ls = rows per clip in memory (>= L, the valid frames): the fine-tuning path keeps every clip on a padded row stride
+__global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__ x, int L, int Ls, int C, int rows_per_block,
                                                        double* __restrict__ sum, double* __restrict__ sq) {
   __shared__ double sh[2][4][64];
   const int b = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const float* __restrict__
   double s = 0.0, q = 0.0;
   if (c < C)
     for (int t = t0 + rg; t < t1; t += 4) {
-      const double v = x[((long long)b * L + t) * C + c];
+      const double v = x[((long long)b * Ls + t) * C + c];
       s += v;
       q += v * v;
     }
@@ -61,18 +62,19 @@ __global__ void colstats_finish_kernel(const double* __restrict__ sum, const dou
   rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 __global__ void colnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, int L, int C, long long n,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int L, int Ls, int C, long long n,
                                      float* __restrict__ y) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
-    const long long bc = (i / C / L) * C + c;
-    y[i] = (x[i] - mean[bc]) * rstd[bc] * gamma[c] + beta[c];
+    const long long row = i / C;
+    const long long bc = (row / Ls) * C + c;
+    y[i] = (row % Ls) < L ? (x[i] - mean[bc]) * rstd[bc] * gamma[c] + beta[c] : 0.f;      // padding rows of a clip: zero
   }
 }
 // backward, pass 1: per (clip, channel) s1 = sum_t dy, s2 = sum_t dy * xhat  (double accumulators, zeroed by the caller)
 __global__ __launch_bounds__(256) void colnorm_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                int L, int C, int rows_per_block, double* __restrict__ s1,
+                                                                int L, int Ls, int C, int rows_per_block, double* __restrict__ s1,
                                                                 double* __restrict__ s2) {
   __shared__ double sh[2][4][64];
   const int b = blockIdx.z, c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void colnorm_bwd_stats_kernel(const float* __r
   if (c < C) {
     const float m = mean[(long long)b * C + c], r = rstd[(long long)b * C + c];
     for (int t = t0 + rg; t < t1; t += 4) {
-      const long long o = ((long long)b * L + t) * C + c;
+      const long long o = ((long long)b * Ls + t) * C + c;
       const double g = dy[o];
       a += g;
       q += g * (double)((x[o] - m) * r);
@@ -99,13 +101,14 @@ __global__ __launch_bounds__(256) void colnorm_bwd_stats_kernel(const float* __r
 // pass 2: dx = gamma * rstd * (dy - s1 / L - xhat * s2 / L)
 __global__ void colnorm_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                         const double* __restrict__ s1, const double* __restrict__ s2, int L, int C, long long n,
+                                         const double* __restrict__ s1, const double* __restrict__ s2, int L, int Ls, int C, long long n,
                                          float* __restrict__ dx) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C);
-    const long long bc = (i / C / L) * C + c;
+    const long long row = i / C;
+    const long long bc = (row / Ls) * C + c;
     const float r = rstd[bc], xh = (x[i] - mean[bc]) * r;
-    dx[i] = gamma[c] * r * (dy[i] - (float)(s1[bc] / L) - xh * (float)(s2[bc] / L));
+    dx[i] = (row % Ls) < L ? gamma[c] * r * (dy[i] - (float)(s1[bc] / L) - xh * (float)(s2[bc] / L)) : 0.f;
   }
 }
 // dgamma[c] (+)= sum_b s2[b][c], dbeta[c] (+)= sum_b s1[b][c]
@@ -186,34 +189,34 @@ extern "C" int ser_gelu_bwd(const float* dy, const float* x, long long n, float*
 
 extern "C" size_t ser_colnorm_workspace_bytes(int B, int C) { return (size_t)2 * B * C * sizeof(double) + 256; }
 
-extern "C" int ser_colnorm_fwd(const float* x, int B, int L, int C, const float* gamma, const float* beta, float eps, float* y,
+extern "C" int ser_colnorm_fwd(const float* x, int B, int L, int Ls, int C, const float* gamma, const float* beta, float eps, float* y,
                                float* mean, float* rstd, void* workspace, void* stream) {
-  SER_REQUIRE(x && y && mean && rstd && workspace && B > 0 && L > 0 && C > 0, "colnorm_fwd: bad argument");
+  SER_REQUIRE(x && y && mean && rstd && workspace && B > 0 && L > 0 && Ls >= L && C > 0, "colnorm_fwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   double* sum = (double*)workspace;
   double* sq = sum + (size_t)B * C;
   SER_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)2 * B * C * sizeof(double), st));
   const int rpb = 512;
-  hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), ceil_div(L, rpb), B), dim3(256), 0, st, x, L, C, rpb, sum, sq);
+  hipLaunchKernelGGL(colstats_kernel, dim3(ceil_div(C, 64), ceil_div(L, rpb), B), dim3(256), 0, st, x, L, Ls, C, rpb, sum, sq);
   hipLaunchKernelGGL(colstats_finish_kernel, dim3(ceil_div(B * C, 256)), dim3(256), 0, st, sum, sq, B * C, L, eps, mean, rstd);
-  const long long n = (long long)B * L * C;
-  hipLaunchKernelGGL(colnorm_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, mean, rstd, gamma, beta, L, C, n, y);
+  const long long n = (long long)B * Ls * C;
+  hipLaunchKernelGGL(colnorm_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, mean, rstd, gamma, beta, L, Ls, C, n, y);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
 
 extern "C" int ser_colnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, int B,
-                               int L, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream) {
-  SER_REQUIRE(dy && x && mean && rstd && gamma && workspace && B > 0 && L > 0 && C > 0, "colnorm_bwd: bad argument");
+                               int L, int Ls, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream) {
+  SER_REQUIRE(dy && x && mean && rstd && gamma && workspace && B > 0 && L > 0 && Ls >= L && C > 0, "colnorm_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   double* s1 = (double*)workspace;
   double* s2 = s1 + (size_t)B * C;
   SER_CHECK_HIP(hipMemsetAsync(workspace, 0, (size_t)2 * B * C * sizeof(double), st));
   const int rpb = 512;
-  hipLaunchKernelGGL(colnorm_bwd_stats_kernel, dim3(ceil_div(C, 64), ceil_div(L, rpb), B), dim3(256), 0, st, dy, x, mean, rstd, L, C,
+  hipLaunchKernelGGL(colnorm_bwd_stats_kernel, dim3(ceil_div(C, 64), ceil_div(L, rpb), B), dim3(256), 0, st, dy, x, mean, rstd, L, Ls, C,
                      rpb, s1, s2);
-  const long long n = (long long)B * L * C;
-  if (dx) hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, x, mean, rstd, gamma, s1, s2, L, C, n, dx);
+  const long long n = (long long)B * Ls * C;
+  if (dx) hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(ew_grid(n)), dim3(256), 0, st, dy, x, mean, rstd, gamma, s1, s2, L, Ls, C, n, dx);
   if (dgamma && dbeta)
     hipLaunchKernelGGL(colnorm_bwd_param_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, s1, s2, B, C, accumulate, dgamma, dbeta);
   SER_LAUNCH_CHECK();

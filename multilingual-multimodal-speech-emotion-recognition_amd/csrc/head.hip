@@ -566,9 +566,12 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_kernel(const float* __restri
 // coalesced.  Same math and same saved tensors (P, dS) as the generic kernels above, which remain the fallback
 // for longer sequences.
 // ------------------------------------------------------------------------------------------
-constexpr int XF_MAXS = 256, XF_HD = 32, XF_LD = XF_MAXS + 1;
+constexpr int XF_MAXS = 256, XF_LD = XF_MAXS + 1;
+// head dimension: 32 (the cross-modal attention's 256 / 8) or 64 (the encoders' self-attention in the fine-tuning path)
+#define XF_HD HD
 
 // grid (ceil(Sq/16), heads, B); 4 waves x 4 query rows
+template <int HD>
 __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                              int ldk, const float* __restrict__ v, int ldv,
                                                              const float* __restrict__ kmask, int Sq, int Sk, int heads,
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __rest
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16;
   const float scale = 1.0f / sqrtf((float)XF_HD);
   for (int idx = tid; idx < Sk * XF_HD; idx += 256) {
-    const int j = idx >> 5, d = idx & 31;
+    const int j = idx / XF_HD, d = idx % XF_HD;
     Kt[d][j] = k[((long long)b * Sk + j) * ldk + h * XF_HD + d];
     Vs[j][d] = v[((long long)b * Sk + j) * ldv + h * XF_HD + d];
   }
@@ -629,17 +632,19 @@ __global__ __launch_bounds__(256) void xattn_fwd_fast_kernel(const float* __rest
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // ctx[d] = sum_j p_j V[j][d]: lanes 0-31 take even keys, 32-63 odd keys
-    const int d = lane & 31, par = lane >> 5;
+    // ctx[d] = sum_j p_j V[j][d]: with 32-wide heads lanes 0-31 take even keys, 32-63 odd keys; 64-wide: one lane per d
+    constexpr int NPAR = 64 / XF_HD;
+    const int d = lane % XF_HD, par = lane / XF_HD;
     float acc = 0.f;
-    for (int j = par; j < Sk; j += 2) acc = fmaf(prow[w][j], Vs[j][d], acc);
-    acc += __shfl_xor(acc, 32, 64);
+    for (int j = par; j < Sk; j += NPAR) acc = fmaf(prow[w][j], Vs[j][d], acc);
+    if (NPAR == 2) acc += __shfl_xor(acc, 32, 64);
     if (lane < XF_HD) ctx[((long long)b * Sq + i) * ldc + h * XF_HD + d] = acc;
     __builtin_amdgcn_wave_barrier();
   }
 }
 
 // per query row: dP = dctx.V^T, dS = P (dP - sum P dP), dq = scale * dS K
+template <int HD>
 __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ k,
                                                                int ldk, const float* __restrict__ v, int ldv,
                                                                const float* __restrict__ P, int Sq, int Sk, int heads,
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __re
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 16;
   const float scale = 1.0f / sqrtf((float)XF_HD);
   for (int idx = tid; idx < Sk * XF_HD; idx += 256) {
-    const int j = idx >> 5, d = idx & 31;
+    const int j = idx / XF_HD, d = idx % XF_HD;
     Vt[d][j] = v[((long long)b * Sk + j) * ldv + h * XF_HD + d];
     Ks[j][d] = k[((long long)b * Sk + j) * ldk + h * XF_HD + d];
   }
@@ -690,17 +695,19 @@ __global__ __launch_bounds__(256) void xattn_bwd_q_fast_kernel(const float* __re
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int d = lane & 31, par = lane >> 5;
+    constexpr int NPAR = 64 / XF_HD;
+    const int d = lane % XF_HD, par = lane / XF_HD;
     float acc = 0.f;
-    for (int j = par; j < Sk; j += 2) acc = fmaf(srow[w][j], Ks[j][d], acc);
-    acc += __shfl_xor(acc, 32, 64);
+    for (int j = par; j < Sk; j += NPAR) acc = fmaf(srow[w][j], Ks[j][d], acc);
+    if (NPAR == 2) acc += __shfl_xor(acc, 32, 64);
     if (lane < XF_HD) dq[((long long)b * Sq + i) * ldq + h * XF_HD + d] = acc * scale;
     __builtin_amdgcn_wave_barrier();
   }
 }
 
 // per key: dk_j = scale * sum_i dS_ij q_i ; dv_j = sum_i P_ij dctx_i.  grid (ceil(Sk/64), heads, B), one key per lane
-// of wave 0..: 256 threads = 4 waves, wave w handles the d-range [8w, 8w+8) for all 64 keys of the tile.
+// of wave 0..: 256 threads = 4 waves, wave w handles the d-range [w HD/4, (w+1) HD/4) for all 64 keys of the tile.
+template <int HD>
 __global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __restrict__ dctx, int ldc, const float* __restrict__ q,
                                                                 int ldq, const float* __restrict__ P, const float* __restrict__ dS,
                                                                 int Sq, int Sk, int heads, float* __restrict__ dk, int ldk,
@@ -711,32 +718,34 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_fast_kernel(const float* __r
   const int b = blockIdx.z, h = blockIdx.y, j = blockIdx.x * 64 + lane;
   const float scale = 1.0f / sqrtf((float)XF_HD);
   for (int idx = tid; idx < Sq * XF_HD; idx += 256) {
-    const int i = idx >> 5, d = idx & 31;
+    const int i = idx / XF_HD, d = idx % XF_HD;
     Qs[i][d] = q[((long long)b * Sq + i) * ldq + h * XF_HD + d];
     Ds[i][d] = dctx[((long long)b * Sq + i) * ldc + h * XF_HD + d];
   }
   __syncthreads();
   const float* Pc = P + ((long long)b * heads + h) * Sq * Sk;
   const float* Sc = dS + ((long long)b * heads + h) * Sq * Sk;
-  float ak[8], av[8];
+  constexpr int DW = XF_HD / 4;          // head dims per wave
+  float ak[DW], av[DW];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ak[e] = av[e] = 0.f;
+  for (int e = 0; e < DW; ++e) ak[e] = av[e] = 0.f;
   const int jj = j < Sk ? j : Sk - 1;
   for (int i = 0; i < Sq; ++i) {
     const float p = Pc[(long long)i * Sk + jj], s = Sc[(long long)i * Sk + jj];     // coalesced over the 64 keys
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      ak[e] = fmaf(s, Qs[i][w * 8 + e], ak[e]);       // LDS broadcast reads
-      av[e] = fmaf(p, Ds[i][w * 8 + e], av[e]);
+    for (int e = 0; e < DW; ++e) {
+      ak[e] = fmaf(s, Qs[i][w * DW + e], ak[e]);       // LDS broadcast reads
+      av[e] = fmaf(p, Ds[i][w * DW + e], av[e]);
     }
   }
   if (j < Sk) {
-    float* dkr = dk + ((long long)b * Sk + j) * ldk + h * XF_HD + w * 8;
-    float* dvr = dv + ((long long)b * Sk + j) * ldv + h * XF_HD + w * 8;
+    float* dkr = dk + ((long long)b * Sk + j) * ldk + h * XF_HD + w * DW;
+    float* dvr = dv + ((long long)b * Sk + j) * ldv + h * XF_HD + w * DW;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dkr[e] = ak[e] * scale; dvr[e] = av[e]; }
+    for (int e = 0; e < DW; ++e) { dkr[e] = ak[e] * scale; dvr[e] = av[e]; }
   }
 }
+#undef XF_HD
 
 // ------------------------------------------------------------------------------------------
 // attentive statistics pooling core (ref src/models/pooling.py:21-28)
@@ -1281,9 +1290,13 @@ extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, c
   const long long rows = (long long)B * heads * Sq;
   if (rows <= 0) return SER_OK;
   const SerDropout drop{(const unsigned long long*)drop_state, drop_site, drop_p};
-  if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
-    hipLaunchKernelGGL(xattn_fwd_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
-                       v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc, drop, P_dropped);
+  if ((head_dim == 32 || head_dim == 64) && Sk <= XF_MAXS && Sq <= XF_MAXS) {
+    if (head_dim == 32)
+      hipLaunchKernelGGL(xattn_fwd_fast_kernel<32>, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
+                         v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc, drop, P_dropped);
+    else
+      hipLaunchKernelGGL(xattn_fwd_fast_kernel<64>, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
+                         v, ldv, key_mask, Sq, Sk, heads, P, ctx, ldc, drop, P_dropped);
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
@@ -1305,11 +1318,18 @@ extern "C" int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq
   const bool dropping = drop_state && drop_p > 0.f;
   SER_REQUIRE(!dropping || P_dropped, "xattn_bwd: dropout needs P_dropped from the forward call");
   const float* Pv = dropping ? P_dropped : P;       // weights of dv = Pv^T dctx
-  if (head_dim == XF_HD && Sk <= XF_MAXS && Sq <= XF_MAXS) {
-    hipLaunchKernelGGL(xattn_bwd_q_fast_kernel, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
-                       Sq, Sk, heads, dS, dq, lddq, drop);
-    hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, Pv, dS, Sq,
-                       Sk, heads, dk, lddk, dv, lddv);
+  if ((head_dim == 32 || head_dim == 64) && Sk <= XF_MAXS && Sq <= XF_MAXS) {
+    if (head_dim == 32) {
+      hipLaunchKernelGGL(xattn_bwd_q_fast_kernel<32>, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
+                         Sq, Sk, heads, dS, dq, lddq, drop);
+      hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel<32>, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, Pv, dS, Sq,
+                         Sk, heads, dk, lddk, dv, lddv);
+    } else {
+      hipLaunchKernelGGL(xattn_bwd_q_fast_kernel<64>, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
+                         Sq, Sk, heads, dS, dq, lddq, drop);
+      hipLaunchKernelGGL(xattn_bwd_kv_fast_kernel<64>, dim3(ceil_div(Sk, 64), heads, B), dim3(256), 0, st, dctx, ldc, q, ldq, Pv, dS, Sq,
+                         Sk, heads, dk, lddk, dv, lddv);
+    }
     SER_LAUNCH_CHECK();
     return SER_OK;
   }

@@ -26,8 +26,8 @@ from .. import _ops as O
 _sig = L._sig
 _sig("ser_gelu_bwd", L.i32, L.vp, L.vp, L.i64, L.vp, L.vp)
 _sig("ser_colnorm_workspace_bytes", L.sz, L.i32, L.i32)
-_sig("ser_colnorm_fwd", L.i32, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.f32, L.vp, L.vp, L.vp, L.vp, L.vp)
-_sig("ser_colnorm_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp)
+_sig("ser_colnorm_fwd", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.f32, L.vp, L.vp, L.vp, L.vp, L.vp)
+_sig("ser_colnorm_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp)
 _sig("ser_toeplitz_add", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 _sig("ser_embed_fwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 _sig("ser_embed_bwd", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp)
@@ -79,43 +79,62 @@ def linear(x, W, b=None):
     return y.reshape(*shp[:-1], W.shape[0])
 
 
-class _ConvWin(torch.autograd.Function):
-    """Conv1d(C_in -> C_out, kernel k, stride s, no padding, no bias) on channels-last x [B, L, C_in] as GEMMs over the
-    strided window view (row t of clip b = x[b, s t : s t + k, :], k*C_in contiguous values, row stride s*C_in): no im2col
-    copy.  W2 [C_out, k*C_in] holds the taps in (tap, channel) order.  Backward: dW2 accumulates dy^T . windows over the clips;
-    dx is one accumulating GEMM per tap, dx[b, s t + j, :] += dy[b, t, :] . W2[:, j*C_in : (j+1)*C_in] — rows of one tap
-    never collide, taps run one after the other on the stream."""
+SLACK = 16      # zero rows behind the last clip of a padded activation buffer (the last windows read past it)
+
+
+def padded_lengths(T, kernels, strides):
+    """Frame counts L[i] of the conv stack and padded per-clip row counts Lp[i] with Lp[i-1] == stride_i * Lp[i]: with every
+    clip of layer i-1 stored on Lp[i-1] rows, window row t of clip b of layer i starts at row s (b Lp[i] + t) of the flat
+    [B * Lp[i-1], C] buffer — ONE strided view for the whole batch, so a conv layer (forward, weight gradient, each tap of
+    the input gradient) is one GEMM instead of one per clip.  The rows t >= L[i] of a clip are padding: they hold finite
+    junk going forward (never read by a valid window: Lp[i-1] >= s (L[i] - 1) + k) and zeros going backward."""
+    L = [int(T)]
+    for k, s_ in zip(kernels, strides):
+        L.append((L[-1] - k) // s_ + 1)
+    n = len(kernels)
+    pad = 0
+    while True:
+        Lp = [0] * (n + 1)
+        Lp[n] = L[n] + pad
+        for i in range(n, 0, -1):
+            Lp[i - 1] = strides[i - 1] * Lp[i]
+        if all(Lp[i - 1] >= strides[i - 1] * (L[i] - 1) + kernels[i - 1] for i in range(1, n + 1)):
+            return L, Lp
+        pad += 1
+
+
+class _ConvPad(torch.autograd.Function):
+    """Conv1d(C_in -> C_out, kernel k, stride s, no padding, no bias), channels-last, whole batch at once on the padded
+    row stride (see padded_lengths): x [rows_in + SLACK, C_in] -> y [rows_out + SLACK, C_out], rows_in = s * rows_out.
+    W2 [C_out, k*C_in] holds the taps in (tap, channel) order.  Forward: one GEMM over the strided window view (row step
+    s*C_in, k*C_in contiguous values: no im2col).  Backward: dW2 = dy^T . windows, one GEMM; dx: one accumulating GEMM per
+    tap, dx[s m + j] += dy[m] . W2[:, j*C_in:(j+1)*C_in] (the rows of one tap never collide, taps follow each other)."""
 
     @staticmethod
-    def forward(ctx, x, W2, k, s):
-        B, Lin, Cin = x.shape
-        Cout = W2.shape[0]
-        Lout = (Lin - k) // s + 1
-        y = torch.empty(B, Lout, Cout, dtype=torch.float32, device=x.device)
-        for b in range(B):
-            _gemm(x[b].data_ptr(), s * Cin, 1, W2.data_ptr(), 1, k * Cin, Lout, Cout, k * Cin, y[b], Cout)
+    def forward(ctx, x, W2, k, s, rows_out):
+        Cin, Cout = x.shape[1], W2.shape[0]
+        assert x.shape[0] >= s * (rows_out - 1) + k
+        y = torch.zeros(rows_out + SLACK, Cout, dtype=torch.float32, device=x.device)
+        _gemm(x.data_ptr(), s * Cin, 1, W2.data_ptr(), 1, k * Cin, rows_out, Cout, k * Cin, y, Cout)
         ctx.save_for_backward(x, W2)
-        ctx.k, ctx.s = k, s
+        ctx.cfg = (k, s, rows_out)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W2 = ctx.saved_tensors
-        k, s = ctx.k, ctx.s
-        B, Lin, Cin = x.shape
-        Cout, Lout = W2.shape[0], dy.shape[1]
+        k, s, rows_out = ctx.cfg
+        Cin, Cout = x.shape[1], W2.shape[0]
         dy = dy.contiguous()
         dW2 = torch.empty_like(W2)
-        for b in range(B):      # dW2[n, kk] (+)= sum_t dy[b, t, n] * win[b, t, kk]
-            _gemm(dy[b].data_ptr(), 1, Cout, x[b].data_ptr(), s * Cin, 1, Cout, k * Cin, Lout, dW2, k * Cin, accumulate=b > 0)
+        _gemm(dy.data_ptr(), 1, Cout, x.data_ptr(), s * Cin, 1, Cout, k * Cin, rows_out, dW2, k * Cin)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.zeros_like(x)
-            for b in range(B):
-                for j in range(k):
-                    _gemm(dy[b].data_ptr(), Cout, 1, W2.data_ptr() + 4 * j * Cin, k * Cin, 1, Lout, Cin, Cout,
-                          dx[b].data_ptr() + 4 * j * Cin, s * Cin, accumulate=True)
-        return dx, dW2, None, None
+            for j in range(k):
+                _gemm(dy.data_ptr(), Cout, 1, W2.data_ptr() + 4 * j * Cin, k * Cin, 1, rows_out, Cin, Cout,
+                      dx.data_ptr() + 4 * j * Cin, s * Cin, accumulate=True)
+        return dx, dW2, None, None, None
 
 
 class _Gelu(torch.autograd.Function):
@@ -165,29 +184,32 @@ class _ColNorm(torch.autograd.Function):
     """GroupNorm(C, C) on channels-last [B, L, C]: per (clip, channel) statistics over time (hf :302-323)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, B, Ln, Ls):
+        """x [>= B*Ls rows, C]: clip b owns rows b*Ls .. b*Ls+Ls-1, the first Ln of them are its frames."""
         x = x.contiguous()
-        B, Ln, Cc = x.shape
-        y = torch.empty_like(x)
+        Cc = x.shape[1]
+        y = torch.zeros_like(x)
         mean = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         ws = torch.empty(int(L.lib.ser_colnorm_workspace_bytes(B, Cc)), dtype=torch.uint8, device=x.device)
-        L.check(L.lib.ser_colnorm_fwd(L.ptr(x), B, Ln, Cc, L.ptr(gamma), L.ptr(beta), eps, L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(ws),
+        L.check(L.lib.ser_colnorm_fwd(L.ptr(x), B, Ln, Ls, Cc, L.ptr(gamma), L.ptr(beta), eps, L.ptr(y), L.ptr(mean), L.ptr(rstd), L.ptr(ws),
                                       L.stream_ptr()), "ser_colnorm_fwd")
         ctx.save_for_backward(x, mean, rstd, gamma)
+        ctx.dims = (B, Ln, Ls)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, mean, rstd, gamma = ctx.saved_tensors
-        B, Ln, Cc = x.shape
+        B, Ln, Ls = ctx.dims
+        Cc = x.shape[1]
         dy = dy.contiguous()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
         dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = torch.empty(int(L.lib.ser_colnorm_workspace_bytes(B, Cc)), dtype=torch.uint8, device=x.device)
-        L.check(L.lib.ser_colnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), B, Ln, Cc, L.ptr(dx), L.ptr(dg),
+        L.check(L.lib.ser_colnorm_bwd(L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), B, Ln, Ls, Cc, L.ptr(dx), L.ptr(dg),
                                       L.ptr(db), 0, L.ptr(ws), L.stream_ptr()), "ser_colnorm_bwd")
-        return dx, dg, db, None
+        return dx, dg, db, None, None, None, None
 
 
 class _Attention(torch.autograd.Function):
@@ -397,15 +419,30 @@ def wav2vec2_forward(model, wave, noise=None):
     eps = c.layer_norm_eps
     x = normalise_waves(wave.to(torch.float32))
     B = x.shape[0]
-    h = x[:, :, None]                                                     # channels-last [B, T, 1]
-    for i, (k, s) in enumerate(zip(c.conv_kernel, c.conv_stride)):
+    Lv, Lp = padded_lengths(x.shape[1], c.conv_kernel, c.conv_stride)
+    # conv0 (1 -> C channels, k 10, s 5): window rows of ALL clips as one strided view of the padded sample buffer; with one
+    # input channel the view is materialised (12 samples per row: the kernel's taps + 2 that meet zero weights) so that the
+    # product and its weight gradient take the head's aligned Linear kernels (split-K over the 100 k rows)
+    k0, s0 = c.conv_kernel[0], c.conv_stride[0]
+    kpad = (k0 + 3) // 4 * 4
+    xp = torch.zeros(B * Lp[0] + SLACK * s0 + kpad, dtype=torch.float32, device=x.device)
+    n0 = min(x.shape[1], Lp[0])
+    xp[:B * Lp[0]].view(B, Lp[0])[:, :n0] = x[:, :n0]
+    X0 = xp.as_strided((B * Lp[1], kpad), (s0, 1)).contiguous()
+    w0 = p["feature_extractor.conv_layers.0.conv.weight"]                 # [C, 1, k]
+    W0 = torch.nn.functional.pad(w0.reshape(w0.shape[0], k0), (0, kpad - k0))
+    h = _Linear.apply(X0, W0.contiguous(), None)
+    h = torch.cat([h, h.new_zeros(SLACK, h.shape[1])], dim=0)
+    h = _ColNorm.apply(h, p["feature_extractor.conv_layers.0.layer_norm.weight"], p["feature_extractor.conv_layers.0.layer_norm.bias"],
+                       1e-5, B, Lv[1], Lp[1])
+    h = gelu(h)
+    for i in range(1, len(c.conv_kernel)):
+        k, s_ = c.conv_kernel[i], c.conv_stride[i]
         w = p[f"feature_extractor.conv_layers.{i}.conv.weight"]           # [C_out, C_in, k]
-        W2 = w.permute(0, 2, 1).reshape(w.shape[0], -1)                   # taps in (tap, channel) order; a view op under autograd
-        h = _ConvWin.apply(h.contiguous(), W2.contiguous(), k, s)
-        if i == 0:
-            h = _ColNorm.apply(h, p["feature_extractor.conv_layers.0.layer_norm.weight"],
-                               p["feature_extractor.conv_layers.0.layer_norm.bias"], 1e-5)
-        h = gelu(h)
+        W2 = w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()      # taps in (tap, channel) order (a view op under autograd)
+        h = gelu(_ConvPad.apply(h, W2, k, s_, B * Lp[i + 1]))                # layer i: Lp[i] rows per clip in, Lp[i + 1] out
+    n = len(c.conv_kernel)
+    h = h[:B * Lp[n]].view(B, Lp[n], -1)[:, :Lv[n], :]
     S = h.shape[1]
     e = layer_norm(h.reshape(B * S, -1), p["feature_projection.layer_norm.weight"], p["feature_projection.layer_norm.bias"], eps)
     z = linear(e, p["feature_projection.projection.weight"], p["feature_projection.projection.bias"])       # [B*S, H]

@@ -184,12 +184,14 @@ def test_gemm_f32_three_forms(M, M_, N, K):
     _close(db, 2 * dy.double().sum(0).float(), atol=1e-5 * M_ ** 0.5 * 4, rtol=2e-4)
 
 
-@pytest.mark.parametrize("Sq,Sk", [(199, 32), (32, 199), (300, 40), (40, 300), (7, 256), (256, 5)])
-def test_xattn_core_fast_and_generic_paths(M, Sq, Sk):
-    """softmax(QK^T/sqrt(d) + mask) V and its backward: S <= 256 runs the LDS-staged kernels, longer sequences the
-    generic ones; both against an fp64 autograd reference."""
+@pytest.mark.parametrize("hd", [32, 64])
+@pytest.mark.parametrize("Sq,Sk", [(199, 32), (32, 199), (300, 40), (40, 300), (7, 256), (256, 5), (199, 199)])
+def test_xattn_core_fast_and_generic_paths(M, Sq, Sk, hd):
+    """softmax(QK^T/sqrt(d) + mask) V and its backward: S <= 256 runs the LDS-staged kernels (32-wide heads: the cross-modal
+    attention; 64-wide: the encoders' self-attention in the fine-tuning path), longer sequences the generic ones; both
+    against an fp64 autograd reference."""
     from ser_amd import _ops as O
-    B, heads, hd = 2, 4, 32
+    B, heads = 2, 4
     E = heads * hd
     g = torch.Generator().manual_seed(Sq * 1000 + Sk)
     q, k, v = (torch.randn(B * n, E, generator=g) for n in (Sq, Sk, Sk))
