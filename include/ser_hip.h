@@ -166,7 +166,8 @@ int ser_xlmr_forward(const SerXlmrConfig* cfg, const SerXlmrWeights* w, const in
 /* Front-end stages on their own (the whole-model entries above call the same launchers):
  * conv0 + GroupNorm + erf-GELU on raw clips, clip normalisation included (hf feature_extraction_wav2vec2.py:78-96 +
  * modeling_wav2vec2.py:302-323) -> channels-last bf16 planes [B, L0, C0], L0 = (T - KW) / ST + 1 (y_lo may be NULL);
- * the zero-padded (clip, group) slab the positional conv GEMM reads (modeling_wav2vec2.py:326-368);
+ * the zero-padded (clip, group) slab the positional conv GEMM reads (modeling_wav2vec2.py:326-368): rows of H/G
+ * channels, or - when slab_lo == slab_hi + 32 (interleaved planes) - rows padded with zeros to a multiple of 32 channels;
  * XLM-R embeddings: position ids + word/type/position gather + LayerNorm (modeling_xlm_roberta.py:75-121,142-155),
  * pos_scratch = B * S ints. */
 size_t ser_conv0_workspace_bytes(int B, int L0, int C0);

@@ -121,8 +121,13 @@ class Wav2Vec2Engine:
         pw = g0 * v0 / torch.sqrt((v0 * v0).sum(dim=(0, 1), keepdim=True))        # [H, Cg, K]
         G = self.cfg.pos_groups
         H, Cg, K = pw.shape
-        pw = pw.reshape(G, H // G, Cg, K).permute(0, 1, 3, 2).reshape(G * (H // G), K * Cg)   # [g][n][j][c]
-        w.pos_w = keep.split(pw, dev, want_lo, planar=True)   # Toeplitz view, row step 48 elements: planar planes
+        pw = pw.reshape(G, H // G, Cg, K).permute(0, 1, 3, 2)                                   # [g][n][j][c]
+        if want_lo:   # three-product mode: pad every tap's Cg channels to a multiple of 32 (zeros) so that the Toeplitz window
+            Cgp = (Cg + L.IL_GROUP - 1) // L.IL_GROUP * L.IL_GROUP      # rows of the slab start on a 32-group: interleaved planes
+            pw = torch.nn.functional.pad(pw, (0, Cgp - Cg)).reshape(G * (H // G), K * Cgp)
+            w.pos_w = keep.split(pw, dev, True)
+        else:
+            w.pos_w = keep.split(pw.reshape(G * (H // G), K * Cg), dev, False)
         w.pos_b = keep.f32(sd["encoder.pos_conv_embed.conv.bias"], dev)
         w.enc_ln_g = keep.f32(sd["encoder.layer_norm.weight"], dev)
         w.enc_ln_b = keep.f32(sd["encoder.layer_norm.bias"], dev)

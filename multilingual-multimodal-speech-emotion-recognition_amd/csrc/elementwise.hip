@@ -558,33 +558,40 @@ int ser_launch_conv0(const float* wave, int B, int T, const float* w, const floa
 // With this layout the im2col row of frame t in group g is the contiguous run
 // slab[b][g][t*Cg : t*Cg + K*Cg], i.e. an NT GEMM with lda = Cg.
 // ------------------------------------------------------------------------------------------
-__global__ void posconv_slab_kernel(const float* __restrict__ z, int B, int S, int H, int G, int K,
+// Cp = channels per slab row in memory (>= Cg; the extra columns are zeros).  With interleaved planes (lo == hi + 32) a row
+// is padded to a multiple of 32 channels so that every Toeplitz window row starts on a 32-group; the padded taps meet
+// zero weights.
+__global__ void posconv_slab_kernel(const float* __restrict__ z, int B, int S, int H, int G, int K, int Cp,
                                     bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
   const int Cg = H / G, R = S + K - 1;
-  const long long total = (long long)B * G * R * Cg;
+  const bool il = ser_is_il(hi, lo);
+  const long long total = (long long)B * G * R * Cp;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Cg);
-    long long r1 = i / Cg;
+    const int c = (int)(i % Cp);
+    long long r1 = i / Cp;
     const int r = (int)(r1 % R);
     r1 /= R;
     const int g = (int)(r1 % G);
     const int b = (int)(r1 / G);
     const int t = r - K / 2;
     float v = 0.f;
-    if (t >= 0 && t < S) v = z[((long long)b * S + t) * H + g * Cg + c];
+    if (c < Cg && t >= 0 && t < S) v = z[((long long)b * S + t) * H + g * Cg + c];
     bf16_t h, l;
     split_bf16(v, h, l);
-    hi[i] = h;
-    if (lo) lo[i] = l;
+    const long long o = il ? ser_il_off(i) : i;
+    hi[o] = h;
+    if (lo) lo[o] = l;
   }
 }
 
 int ser_launch_posconv_slab(const float* z, int B, int S, int H, int G, int K, bf16_t* hi, bf16_t* lo, hipStream_t st) {
-  const long long total = (long long)B * (S + K - 1) * H;
+  const int Cg = H / G;
+  const int Cp = ser_is_il(hi, lo) ? (Cg + SER_IL_GROUP - 1) / SER_IL_GROUP * SER_IL_GROUP : Cg;
+  const long long total = (long long)B * G * (S + K - 1) * Cp;
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(posconv_slab_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, B, S, H, G, K, hi, lo);
+  hipLaunchKernelGGL(posconv_slab_kernel, dim3((unsigned)blocks), dim3(256), 0, st, z, B, S, H, G, K, Cp, hi, lo);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

@@ -207,7 +207,11 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
   float* feat = ar.get<float>(rows * Cl);
   Planes featn = take_planes(ar, rows * Cl, x3);
   float* z = ar.get<float>(rows * H);
-  Planes slab = take_planes(ar, (size_t)B * G * (S + Kp - 1) * Cg, x3, /*planar=*/true);
+  // positional-conv slab: in three-product mode its rows are padded from Cg to Cgp (a multiple of 32) channels so that the
+  // Toeplitz windows start on a 32-group and the interleaved kernel applies (+ K rows of slack behind the last window)
+  const bool pos_il = x3 && ser_is_il(w ? w->pos_w.hi : nullptr, w ? w->pos_w.lo : nullptr);
+  const int Cgp = (x3 && (!w || pos_il)) ? (Cg + SER_IL_GROUP - 1) / SER_IL_GROUP * SER_IL_GROUP : Cg;
+  Planes slab = take_planes(ar, (size_t)B * G * (S + Kp - 1) * Cgp + (size_t)Kp * Cgp, x3, /*planar=*/x3 && w && !pos_il);
   float* hsum = ar.get<float>(rows * H);
   float* ha = ar.get<float>(rows * H);
   float* hb = ar.get<float>(rows * H);
@@ -249,10 +253,10 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
   SER_TRY(ser_launch_posconv_slab(z, B, S, H, G, Kp, slab.hi, slab.lo, st));
   {
     const long long R = S + Kp - 1;
-    SerGemmArgs g = gemm_args(slab, Cg, w->pos_w, Kp * Cg, S, Cg, Kp * Cg);
+    SerGemmArgs g = gemm_args(slab, Cgp, w->pos_w, Kp * Cgp, S, Cg, Kp * Cgp);
     g.nb1 = B; g.nb2 = G;
-    g.sa1 = (long long)G * R * Cg; g.sa2 = R * Cg;
-    g.sw1 = 0; g.sw2 = (long long)Cg * Kp * Cg;
+    g.sa1 = (long long)G * R * Cgp; g.sa2 = R * Cgp;
+    g.sw1 = 0; g.sw2 = (long long)Cg * Kp * Cgp;
     g.bias = w->pos_b; g.sbias1 = 0; g.sbias2 = Cg;
     g.act = SER_ACT_GELU;
     g.residual = z; g.ldr = H; g.sr1 = (long long)S * H; g.sr2 = Cg;
