@@ -374,6 +374,37 @@ int ser_eval_consumers(const float* logits, int B, int C, float temperature, flo
 int ser_temperature_grid(const float* logits, const int64_t* labels, int N, int C, const float* temps, int G, float* ece,
                          void* stream);
 
+/* Quality-gate / audio-conditioning front end of the reference's default AudioEncoder(), batched
+ * over B equal-length clips of T >= 2048 samples at 16 kHz, no host synchronisation; one workspace of
+ * ser_frontend_workspace_bytes(B, T) serves both calls.  ser_frontend_init uploads the FFT tables (call once, outside any
+ * stream capture; the two calls below do it on first use otherwise).
+ *
+ * ser_quality_gates (ref src/models/quality_gates.py:497-560, vad_method = "librosa"): energy VAD (:111-137), STFT SNR
+ * (:189-214), clipping (:216-226), spectral naturalness (:228-247), music / laughter scores (:320-345), abstain policy and
+ * quality score (:347-403).  lid[b] = {language entropy, dominant-language confidence} of clip b's transcript as
+ * LanguageIdentifier.identify_language returns them (:252-301; {1.0, 0.0} without text, :514-517).  pad_reflect: 0 = the
+ * zero centre padding of librosa >= 0.10, 1 = the reflect padding of 0.9.x.
+ *   q_raw     [B, 8]  inputs of quality_projection in the reference's order (:544-553)
+ *   q_metrics [B, 8]  speech_prob, snr_db, clipping_percent, spectral_naturalness, music_prob, laughter_prob,
+ *                     quality_score, decision (may be NULL)
+ *   decision  [B]     0 reject, 1 uncertain, 2 accept
+ *
+ * ser_audio_conditioning (ref src/models/audio_conditioning.py:503-584 with noisereduce / pyloudnorm absent): hum notch
+ * (:66-95), high-pass (:107-150), energy SNR + Wiener denoise (:161-215, :244-256), T60 estimate (:274-301), loudness
+ * normalisation with compression (:364-440).  decision (may be NULL): clips whose entry is not 2 are processed as all-zero
+ * audio, as AudioEncoder.forward substitutes them (src/models/audio_encoder.py:74-77).
+ *   out    [B, T]   conditioned clips
+ *   c_raw  [B, 12]  inputs of conditioning_projection in the reference's order (:562-575)
+ *   c_meta [B, 12]  hpf_cutoff, hum50, hum60, snr_before, snr_after, denoise_gain_db, estimated_t60, lufs_original,
+ *                   lufs_adjustment, peak_reduction_db, compression_ratio, noise type (0 unknown, 1 low_frequency,
+ *                   2 high_frequency, 3 mid_frequency, 4 white_noise) (may be NULL) */
+size_t ser_frontend_workspace_bytes(int B, int T);
+int ser_frontend_init(void);
+int ser_quality_gates(const float* wave, int B, int T, int sample_rate, const float* lid, int pad_reflect, float* q_raw,
+                      float* q_metrics, int* decision, void* workspace, size_t workspace_bytes, void* stream);
+int ser_audio_conditioning(const float* wave, const int* decision, int B, int T, int sample_rate, float* out, float* c_raw,
+                           float* c_meta, void* workspace, size_t workspace_bytes, void* stream);
+
 /* HIP-event timing of every ser_gemm_f32-family launch between start and stop (measurement aid). */
 int ser_prof_gemm_f32_start(void);
 int ser_prof_gemm_f32_stop(double* total_ms, double* total_flops, long long* launches);

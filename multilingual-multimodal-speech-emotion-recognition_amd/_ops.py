@@ -478,3 +478,51 @@ def temperature_grid(logits, labels, temps):
     L.check(L.lib.ser_temperature_grid(L.ptr(logits), L.ptr(labels), logits.shape[0], logits.shape[1], L.ptr(temps), temps.numel(),
                                        L.ptr(ece), L.stream_ptr()), "ser_temperature_grid")
     return ece
+
+
+# ---- quality-gate / audio-conditioning front end (csrc/frontend.hip) ----------------------------------------------------
+L._sig("ser_frontend_workspace_bytes", L.sz, L.i32, L.i32)
+L._sig("ser_frontend_init", L.i32)
+L._sig("ser_quality_gates", L.i32, L.vp, L.i32, L.i32, L.i32, L.vp, L.i32, L.vp, L.vp, L.vp, L.vp, L.sz, L.vp)
+L._sig("ser_audio_conditioning", L.i32, L.vp, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp, L.sz, L.vp)
+_FE_WS = {}
+
+
+def _frontend_ws(B, T, dev):
+    need = L.lib.ser_frontend_workspace_bytes(B, T)
+    ws = _FE_WS.get(dev)
+    if ws is None or ws.numel() < need:
+        L.check(L.lib.ser_frontend_init(), "ser_frontend_init")
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        _FE_WS[dev] = ws
+    return ws, need
+
+
+def quality_gates(wave, lid, pad_mode="constant", sample_rate=16000):
+    """wave [B, T] f32, lid [B, 2] (language entropy, confidence) -> (q_raw [B, 8], metrics [B, 8], decision int32 [B])
+    (ref quality_gates.py:497-560, energy VAD)."""
+    wave, lid = _c(wave), _c(lid.to(torch.float32))
+    B, T = wave.shape
+    assert lid.shape == (B, 2)
+    raw, met = empty(B, 8, like=wave), empty(B, 8, like=wave)
+    dec = torch.empty(B, dtype=torch.int32, device=wave.device)
+    ws, need = _frontend_ws(B, T, wave.device)
+    L.check(L.lib.ser_quality_gates(L.ptr(wave), B, T, int(sample_rate), L.ptr(lid), 1 if pad_mode == "reflect" else 0, L.ptr(raw),
+                                    L.ptr(met), L.ptr(dec), L.ptr(ws), need, L.stream_ptr()), "ser_quality_gates")
+    return raw, met, dec
+
+
+def audio_conditioning(wave, decision=None, sample_rate=16000):
+    """wave [B, T] f32 (+ decision int32 [B]: clips not marked 2 = 'accept' are conditioned as silence) ->
+    (conditioned [B, T], c_raw [B, 12], meta [B, 12])  (ref audio_conditioning.py:503-584)."""
+    wave = _c(wave)
+    B, T = wave.shape
+    out = torch.empty_like(wave)
+    raw, meta = empty(B, 12, like=wave), empty(B, 12, like=wave)
+    if decision is not None:
+        decision = _c(decision.to(torch.int32))
+    ws, need = _frontend_ws(B, T, wave.device)
+    L.check(L.lib.ser_audio_conditioning(L.ptr(wave), L.ptr(decision) if decision is not None else None, B, T, int(sample_rate),
+                                         L.ptr(out), L.ptr(raw), L.ptr(meta), L.ptr(ws), need, L.stream_ptr()),
+            "ser_audio_conditioning")
+    return out, raw, meta

@@ -73,13 +73,17 @@ def main(argv=None):
     p.add_argument('--audio_model', type=str, default='facebook/wav2vec2-base')
     p.add_argument('--text_model', type=str, default='xlm-roberta-base')
     p.add_argument('--precision', choices=['bf16x3', 'bf16'], default='bf16x3')
+    p.add_argument('--use_quality_gates', action='store_true', help="quality gates of the reference's default AudioEncoder() (device kernels)")
+    p.add_argument('--use_audio_conditioning', action='store_true', help="audio conditioning of the reference's default AudioEncoder() (device kernels)")
+    p.add_argument('--vad_method', type=str, default='webrtc')
     args = p.parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("the HIP hot path needs an MI355X; there is no CPU fallback")
     device = torch.device("cuda")
     ck = torch.load(args.checkpoint, map_location=device, weights_only=False)
     num_labels = ck['classifier']['weibull_alpha'].numel()
-    ae = AudioEncoder(args.audio_model, use_quality_gates=False, use_audio_conditioning=False, precision=args.precision)
+    ae = AudioEncoder(args.audio_model, use_quality_gates=args.use_quality_gates, vad_method=args.vad_method,
+                      use_audio_conditioning=args.use_audio_conditioning, precision=args.precision)
     te = TextEncoder(args.text_model, precision=args.precision)
     sysm = SERSystem(ae, te, num_labels=num_labels).to(device)
     sysm.load_checkpoint_dict(ck)

@@ -10,10 +10,11 @@ the model is per clip).
 Differences, all recorded in DESIGN.md:
   * frozen encoder (`freeze_base=True`, the reference default) runs in eval semantics without a
     backward pass; the reference back-propagates through it only to discard the result.
-  * the CPU DSP side-cars (quality gates, audio conditioning; ref :25-52, :67-86) need
-    librosa/webrtcvad/scipy pipelines that are outside the hot path: the two flags exist, the
-    learnable projection/fusion layers are created with the reference's key names when they are on,
-    but the forward requires them off (`use_quality_gates=False, use_audio_conditioning=False`).
+  * the DSP side-cars (quality gates, audio conditioning; ref :25-52, :67-86) run as batched device
+    kernels (`models/frontend.py`, `csrc/frontend.hip`) instead of per-clip numpy / librosa / scipy
+    on the host; `gate_features=(quality_raw, conditioning_raw)` lets a caller supply the raw feature
+    vectors instead (then the audio is used as given).  See models/frontend.py for the webrtcvad /
+    langdetect / noisereduce notes.
 """
 from typing import List, Optional
 
@@ -24,15 +25,8 @@ from .. import _lib as L
 from .. import _ops as O
 from .._engines import Wav2Vec2Engine
 from .adapter import adapter_apply
+from .frontend import create_audio_conditioning, create_quality_gates
 from .pooling import AttentiveStatsPooling
-
-
-class _ProjectionHolder(nn.Module):
-    """Key-compatible holder for `quality_gates.quality_projection` / `audio_conditioning.conditioning_projection`."""
-
-    def __init__(self, name, dim):
-        super().__init__()
-        setattr(self, name, nn.Sequential(nn.Linear(dim, 32), nn.ReLU(), nn.Dropout(0.1), nn.Linear(32, dim)))
 
 
 class _GateFusionFn(torch.autograd.Function):
@@ -109,11 +103,11 @@ class AudioEncoder(nn.Module):
         self.pool = AttentiveStatsPooling(hid)
         self.use_quality_gates = use_quality_gates
         if use_quality_gates:
-            self.quality_gates = _ProjectionHolder("quality_projection", 8)
+            self.quality_gates = create_quality_gates(vad_method=vad_method)
             self.quality_fusion = nn.Sequential(nn.Linear(hid + 8, hid), nn.ReLU(), nn.Dropout(0.1))
         self.use_audio_conditioning = use_audio_conditioning
         if use_audio_conditioning:
-            self.audio_conditioning = _ProjectionHolder("conditioning_projection", 12)
+            self.audio_conditioning = create_audio_conditioning()
             self.conditioning_fusion = nn.Sequential(nn.Linear(hid + 12, hid), nn.ReLU(), nn.Dropout(0.1))
         if use_quality_gates and use_audio_conditioning:
             self.combined_fusion = nn.Sequential(nn.Linear(hid + 20, hid), nn.ReLU(), nn.Dropout(0.1))
@@ -149,6 +143,20 @@ class AudioEncoder(nn.Module):
             seq = self.engine().forward(wave)
         return adapter_apply(self, seq)
 
+    def front_end(self, wave: torch.Tensor, texts=None):
+        """[B,T] equal-length clips -> (audio for the encoder, quality_raw [B,8] | None, conditioning_raw [B,12] | None,
+        decision int32 [B] | None): ref :67-86 for a whole batch, no host round trip."""
+        q_raw = c_raw = dec = None
+        if self.use_quality_gates:
+            _, q, accept = self.quality_gates(wave, texts)
+            q_raw, dec = q.features, q.decision
+            if not self.use_audio_conditioning:
+                wave = wave * accept.to(wave.dtype)[:, None]          # ref :74-77
+        if self.use_audio_conditioning:
+            wave, c = self.audio_conditioning(wave, dec)             # clips not accepted enter as silence
+            c_raw = c.features
+        return wave, q_raw, c_raw, dec
+
     def _fusion_layer(self, has_q, has_c):
         return self.combined_fusion if (has_q and has_c) else (self.quality_fusion if has_q else self.conditioning_fusion)
 
@@ -168,14 +176,12 @@ class AudioEncoder(nn.Module):
         return _GateFusionFn.apply(self, seq, quality_raw, conditioning_raw, *self._gate_flat.params)
 
     def forward(self, audio_waveforms: List[torch.Tensor], texts: Optional[List[str]] = None, gate_features=None):
-        """gate_features: (quality_raw [B,8] or None, conditioning_raw [B,12] or None) — the raw feature vectors the
-        reference's CPU DSP front end computes per clip (quality_gates.py:544-553, audio_conditioning.py:562-577).
-        Required when the gate flags are on: the DSP itself is not part of the HIP path (see module docstring)."""
+        """With the gate flags on, every clip goes through the quality gates (clips that are not accepted become silence,
+        ref :67-77) and the audio conditioning (ref :81-86) on the device before the encoder, and the projected features
+        are fused into the sequence (ref :113-132).  gate_features = (quality_raw [B,8] or None, conditioning_raw [B,12]
+        or None) overrides that: the audio is encoded as given and these raw feature vectors are fused."""
         gates_on = self.use_quality_gates or self.use_audio_conditioning
-        if gates_on and gate_features is None:
-            raise NotImplementedError(
-                "the CPU DSP quality-gate / audio-conditioning front end is outside the HIP hot path; construct with "
-                "use_quality_gates=False, use_audio_conditioning=False, or pass gate_features=(quality_raw, conditioning_raw)")
+        run_front_end = gates_on and gate_features is None
         dev = self.adapter[0].weight.device
         if isinstance(audio_waveforms, torch.Tensor) and audio_waveforms.dim() == 2:
             groups = {int(audio_waveforms.shape[1]): (list(range(audio_waveforms.shape[0])), audio_waveforms.to(dev))}
@@ -188,8 +194,20 @@ class AudioEncoder(nn.Module):
             groups = {T: (idx, torch.stack([audio_waveforms[i].reshape(-1).to(dev, torch.float32) for i in idx]))
                       for T, idx in by_len.items()}
         outs = [None] * n
+        if run_front_end:
+            q_all = torch.zeros(n, 8, dtype=torch.float32, device=dev) if self.use_quality_gates else None
+            c_all = torch.zeros(n, 12, dtype=torch.float32, device=dev) if self.use_audio_conditioning else None
+            self.last_decisions = torch.full((n,), 2, dtype=torch.int32, device=dev)
+            gate_features = (q_all, c_all)
         for T, (idx, wave) in groups.items():
-            seq = self.encode(wave.to(torch.float32))
+            wave = wave.to(torch.float32)
+            if run_front_end:
+                wave, q_raw, c_raw, dec = self.front_end(wave, [texts[i] if i < len(texts) else None for i in idx] if texts else None)
+                whole = idx == list(range(n))
+                for dst, src in ((q_all, q_raw), (c_all, c_raw), (self.last_decisions, dec)):
+                    if src is not None:
+                        dst.copy_(src) if whole else dst.index_copy_(0, torch.tensor(idx, device=dev), src)
+            seq = self.encode(wave)
             for j, i in enumerate(idx):
                 outs[i] = seq[j]
         if len(groups) == 1:

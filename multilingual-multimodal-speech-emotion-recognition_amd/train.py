@@ -65,6 +65,11 @@ def build_parser():
     p.add_argument('--synthetic_seconds', type=str, default='4', help='duration(s) of the synthetic clips, comma separated (ragged corpus)')
     p.add_argument('--graph', action='store_true')
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--use_quality_gates', action='store_true',
+                   help="the reference AudioEncoder()'s quality gates (VAD / SNR / clipping / spectral checks, ref quality_gates.py) as device kernels")
+    p.add_argument('--use_audio_conditioning', action='store_true',
+                   help="the reference AudioEncoder()'s audio conditioning (hum notch, high-pass, Wiener, loudness, ref audio_conditioning.py) as device kernels")
+    p.add_argument('--vad_method', type=str, default='webrtc', help="'webrtc' (reference default; the energy VAD is substituted) or 'librosa'")
     p.add_argument('--no_bucketing', action='store_true', help='plain shuffled batches instead of length-bucketed ones')
     p.add_argument('--unfreeze_encoders', action='store_true',
                    help='BASELINE config 3: full fine-tune, every Wav2Vec2 / XLM-R parameter trained (reference freeze_base=False)')
@@ -129,7 +134,11 @@ class HipEngine:
         torch.manual_seed(args.seed)               # identical initial replicas on every rank
         self.args, self.device, self.rank = args, device, rank
         frozen = not args.unfreeze_encoders
-        ae = AudioEncoder(args.audio_model, use_quality_gates=False, use_audio_conditioning=False, precision=args.precision, freeze_base=frozen)
+        # the reference's train.py builds AudioEncoder() with its defaults (quality gates + audio conditioning on, ref :54);
+        # here they are opt-in flags because they silence every clip that comes with a transcript
+        ae = AudioEncoder(args.audio_model, use_quality_gates=args.use_quality_gates, vad_method=args.vad_method,
+                          use_audio_conditioning=args.use_audio_conditioning, precision=args.precision, freeze_base=frozen)
+        self.gated = args.use_quality_gates or args.use_audio_conditioning
         self.te = TextEncoder(args.text_model, precision=args.precision, freeze_base=frozen)
         self.sys = SERSystem(ae, self.te, num_labels=args.num_labels).to(device)
         self.sys.dropout_seed += rank              # every data-parallel rank draws its own dropout masks
@@ -170,9 +179,11 @@ class HipEngine:
             wave = torch.stack(audio_list).to(dev)
             if self.aug:
                 wave = self.aug.device(wave, noise_seed=(epoch * 1000003 + step) * 64 + self.rank)
-            return self.stepper.step(wave, ids, mask, labels.to(dev))
-        # ragged clips: the reference's pad-to-longest semantics (one encoder pass per distinct length), eager launches
-        if self.aug:
+            if not self.gated:
+                return self.stepper.step(wave, ids, mask, labels.to(dev))
+            audio_list = wave                      # the gate / conditioning kernels + feature fusion run in AudioEncoder.forward
+        elif self.aug:
+            # ragged clips: the reference's pad-to-longest semantics (one encoder pass per distinct length), eager launches
             audio_list = self.aug.host(audio_list)
         self.opt.zero_grad(set_to_none=True)
         if self.reducer:

@@ -50,8 +50,32 @@ def test_encoder_wrappers_keep_reference_keys():
               "audio_conditioning.conditioning_projection.0.weight", "conditioning_fusion.0.weight", "combined_fusion.0.weight"):
         assert k in keys
     assert ae2.state_dict()["combined_fusion.0.weight"].shape == (128, 148)
-    with pytest.raises(NotImplementedError):
+    from ser_amd.models.frontend import AudioConditioningModule, FrontEndQualityGates
+    assert isinstance(ae2.quality_gates, FrontEndQualityGates) and isinstance(ae2.audio_conditioning, AudioConditioningModule)
+    from ser_amd._lib import SerHipError
+    with pytest.raises((AssertionError, SerHipError)):     # the front end is device kernels: no device / CPU tensors -> refused, no fallback
         ae2([torch.zeros(4000)])
+    with pytest.raises(ValueError, match="VAD method"):
+        AudioEncoder(hf_config=wc, adapter_dim=32, vad_method="silero")
+
+
+def test_language_features_follow_the_reference_table():
+    """ref quality_gates.py:252-301, :514-517 — pinned by tests/test_oracle_dsp.py through the same numbers."""
+    import numpy as np
+    from ser_amd.models.frontend import LID_LISTED, LID_OTHER, language_features
+    G = np.load(os.path.join(GOLDEN, "dsp_frontend.npz"))
+    rows = G["qg.lid"]                     # (langdetect available?, entropy, confidence) for: unavailable, en, ja, hi
+    lf = language_features(["some words"] * 3 + [None, "   ", "x"], 6, detector=lambda t: {"some words": "en"}.get(t, "hi"))
+    assert lf[0].tolist() == pytest.approx([rows[1][1], rows[1][2]], abs=1e-6)
+    assert list(LID_LISTED) == pytest.approx([rows[1][1], rows[1][2]], abs=1e-9)
+    assert list(LID_OTHER) == pytest.approx([rows[3][1], rows[3][2]], abs=1e-9)
+    assert lf[3].tolist() == [1.0, 0.0] and lf[4].tolist() == [1.5, 0.0] and lf[5].tolist() == pytest.approx(list(LID_OTHER), abs=1e-6)
+    none = language_features(["some words"], 1, detector=None)
+    from ser_amd.models import frontend as FE
+    if FE._langdetect is None:
+        assert none[0].tolist() == pytest.approx([rows[0][1], rows[0][2]])
+    boom = language_features(["x"], 1, detector=lambda t: 1 / 0)
+    assert boom[0].tolist() == [1.5, 0.0]
 
 
 def test_flat_params_views_roundtrip_and_reflatten():
