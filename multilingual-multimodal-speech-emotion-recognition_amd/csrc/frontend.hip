@@ -24,8 +24,10 @@
 namespace {
 
 constexpr int NFFT = 2048;
-constexpr int FE_T = 256;          // threads of the per-frame and per-clip kernels
+constexpr int FE_T = 256;          // threads of the per-frame (FFT, rms) kernels
+constexpr int FE_C = 1024;         // threads of the one-workgroup-per-clip kernels (statistics, decisions)
 constexpr int FE_IIR_T = 512;      // threads (= chunks) of the filter / scan kernels
+constexpr int FE_CAND = 1024;      // radix select: candidates that are finished by direct ranking in LDS
 
 struct FeTables {
   double2 tw[NFFT / 2];            // exp(-2 pi i k / 2048)
@@ -99,52 +101,96 @@ SER_DEVFN unsigned long long block_min_u64(unsigned long long v, double* red) {
   return r[0];
 }
 
-// k-th smallest (0-based) and its successor among n non-negative values v(i) (a radix select on the bit patterns, 8 bits
-// per pass), then numpy's 'linear' percentile interpolation (numpy/lib/_function_base_impl.py _lerp).
+// k-th smallest (0-based) and its successor among n non-negative values v(i), then numpy's 'linear' percentile
+// interpolation (numpy/lib/_function_base_impl.py _lerp).  A radix select on the IEEE bit patterns, 8 bits per pass; squared
+// samples share their leading bits, so the histogram increments are combined per wave (one atomic per distinct digit in
+// the wave) and, as soon as at most FE_CAND elements share the prefix, those are gathered into LDS and ranked directly.
+struct SelectLds {
+  unsigned hist[256];
+  unsigned long long bc[2];
+  unsigned long long cand[FE_CAND];
+  unsigned ncand;
+};
+SER_DEVFN void wave_hist_add(unsigned* hist, bool active, unsigned digit) {
+  // one combined increment for the digit of the first active lane (squared samples: usually the whole wave), plain LDS
+  // atomics for the lanes that differ (few, or spread over many counters)
+  const unsigned long long todo = __ballot(active);
+  if (!todo) return;
+  const int leader = __ffsll((long long)todo) - 1;
+  const unsigned d = (unsigned)__shfl((int)digit, leader, 64);
+  const unsigned long long same = __ballot(active && digit == d);
+  if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[d], (unsigned)__popcll(same));
+  else if (active && digit != d) atomicAdd(&hist[digit], 1u);
+}
 template <typename F>
-SER_DEVFN double block_percentile(F v, int n, double q, unsigned* hist /*[256]*/, double* red, unsigned long long* bc /*[2]*/) {
+SER_DEVFN double block_percentile(F v, int n, double q, SelectLds& S, double* red) {
   const double vi = (double)(n - 1) * (q / 100.0);
   int k = (int)floor(vi);
   const double gamma = vi - (double)k;
-  const int k0 = k;
+  const int k0 = k, nt = blockDim.x, t = threadIdx.x;
   unsigned long long prefix = 0, mask = 0;
-  unsigned eq = 0;
-  for (int shift = 56; shift >= 0; shift -= 8) {
+  unsigned group = (unsigned)n;                   // elements whose key matches the prefix
+  int shift = 56;
+  for (; shift >= 0 && group > FE_CAND; shift -= 8) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    for (int i = t; i < 256; i += nt) S.hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const unsigned long long key = (unsigned long long)__double_as_longlong(v(i));
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    for (int base = 0; base < n; base += nt) {
+      const int i = base + t;
+      unsigned long long key = 0;
+      if (i < n) key = (unsigned long long)__double_as_longlong(v(i));
+      wave_hist_add(S.hist, i < n && (key & mask) == prefix, (unsigned)(key >> shift) & 255u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (t == 0) {
       unsigned cum = 0;
       int d = 0;
       for (; d < 255; ++d) {
-        if (cum + hist[d] > (unsigned)k) break;
-        cum += hist[d];
+        if (cum + S.hist[d] > (unsigned)k) break;
+        cum += S.hist[d];
       }
-      bc[0] = (unsigned long long)d;
-      bc[1] = ((unsigned long long)cum << 32) | hist[d];
+      S.bc[0] = (unsigned long long)d;
+      S.bc[1] = ((unsigned long long)cum << 32) | S.hist[d];
     }
     __syncthreads();
-    const unsigned long long d = bc[0];
-    k -= (int)(bc[1] >> 32);
-    eq = (unsigned)(bc[1] & 0xffffffffu);
-    prefix |= d << shift;
+    k -= (int)(S.bc[1] >> 32);
+    group = (unsigned)(S.bc[1] & 0xffffffffu);
+    prefix |= S.bc[0] << shift;
     mask |= 255ull << shift;
   }
-  const double a = __longlong_as_double((long long)prefix);
-  double b = a;
-  if (k0 + 1 < n && (unsigned)(k + 1) >= eq) {      // the successor is the smallest value above a
-    unsigned long long best = ~0ull;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  unsigned long long ka = prefix, kb = prefix;
+  bool have_next = (unsigned)(k + 1) < group;     // all 64 bits fixed: the group is `group` copies of one value
+  if (shift >= 0) {                               // rank the remaining candidates in LDS
+    __syncthreads();
+    if (t == 0) S.ncand = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += nt) {
       const unsigned long long key = (unsigned long long)__double_as_longlong(v(i));
-      if (key > prefix && key < best) best = key;
+      if ((key & mask) == prefix) S.cand[atomicAdd(&S.ncand, 1u)] = key;
     }
-    b = __longlong_as_double((long long)block_min_u64(best, red));
+    __syncthreads();
+    const int m = (int)S.ncand;
+    for (int c = t; c < m; c += nt) {
+      const unsigned long long key = S.cand[c];
+      int r = 0;
+      for (int j = 0; j < m; ++j) r += (S.cand[j] < key) || (S.cand[j] == key && j < c);
+      if (r == k) S.bc[0] = key;
+      if (r == k + 1) S.bc[1] = key;
+    }
+    __syncthreads();
+    ka = S.bc[0];
+    have_next = k + 1 < m;
+    kb = have_next ? S.bc[1] : ka;
   }
+  if (!have_next && k0 + 1 < n) {                 // the successor lies outside the group: smallest key above ka
+    unsigned long long best = ~0ull;
+    for (int i = t; i < n; i += nt) {
+      const unsigned long long key = (unsigned long long)__double_as_longlong(v(i));
+      if (key > ka && key < best) best = key;
+    }
+    kb = block_min_u64(best, red);
+  }
+  const double a = __longlong_as_double((long long)ka), b = __longlong_as_double((long long)kb);
   const double d = b - a;
   return gamma >= 0.5 ? b - d * (1.0 - gamma) : a + d * gamma;
 }
@@ -263,17 +309,17 @@ __global__ __launch_bounds__(FE_T) void fe_fft_kernel(const void* __restrict__ s
 // density scaling, one-sided) and the decision the reference takes from it -----------------------------------------------
 enum { WELCH_HUM = 0, WELCH_HPF = 1, WELCH_NOISE = 2 };
 
-__global__ __launch_bounds__(FE_T) void fe_welch_kernel(const double* __restrict__ power, int nseg, int N, double fs,
+__global__ __launch_bounds__(FE_C) void fe_welch_kernel(const double* __restrict__ power, int nseg, int N, double fs,
                                                          const FeTables* __restrict__ tab, int mode, CondState* __restrict__ st) {
   __shared__ double psd[NFFT / 2 + 1];
-  __shared__ double red[FE_T];
+  __shared__ double red[FE_C];
   const int b = blockIdx.x, t = threadIdx.x, NB = N / 2 + 1, tws = NFFT / N;
   double w2 = 0;
-  for (int n = t; n < N; n += FE_T) w2 += tab->hann[n * tws] * tab->hann[n * tws];
+  for (int n = t; n < N; n += FE_C) w2 += tab->hann[n * tws] * tab->hann[n * tws];
   const double scale = 1.0 / (fs * block_sum(w2, red));
   const double* p = power + (long long)b * nseg * NB;
   double tot = 0;
-  for (int k = t; k < NB; k += FE_T) {
+  for (int k = t; k < NB; k += FE_C) {
     double a = 0;
     for (int s = 0; s < nseg; ++s) a += p[(long long)s * NB + k];
     a = a / nseg * scale * ((k == 0 || k == N / 2) ? 1.0 : 2.0);
@@ -286,7 +332,7 @@ __global__ __launch_bounds__(FE_T) void fe_welch_kernel(const double* __restrict
   if (mode == WELCH_HUM) {                       // ref audio_conditioning.py:66-82
     const double mean = total / NB;
     double dv = 0;
-    for (int k = t; k < NB; k += FE_T) dv += (psd[k] - mean) * (psd[k] - mean);
+    for (int k = t; k < NB; k += FE_C) dv += (psd[k] - mean) * (psd[k] - mean);
     const double thr = mean + 2.0 * sqrt(block_sum(dv, red) / NB);
     if (t == 0) {
       for (int h = 0; h < 2; ++h) {
@@ -298,31 +344,41 @@ __global__ __launch_bounds__(FE_T) void fe_welch_kernel(const double* __restrict
     }
   } else if (mode == WELCH_HPF) {                // ref :107-137
     double low = 0;
-    for (int k = t; k < NB; k += FE_T)
+    for (int k = t; k < NB; k += FE_C)
       if (k * df < 200.0) low += psd[k];
     low = block_sum(low, red);
+    // first bin whose running sum exceeds 10 % of the total (np.cumsum + np.where, ref :125-133): each thread owns a run
+    // of consecutive bins, the run totals are scanned, the crossing is the smallest index any run reports
+    const int per = (NB + FE_C - 1) / FE_C, k0 = t * per, k1 = min(NB, k0 + per);
+    double mine = 0;
+    for (int k = k0; k < k1; ++k) mine += psd[k];
+    __syncthreads();
+    red[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < FE_C; o <<= 1) {
+      const double add = t >= o ? red[t - o] : 0.0;
+      __syncthreads();
+      red[t] += add;
+      __syncthreads();
+    }
+    const double thr = 0.1 * red[FE_C - 1];
+    double run = t > 0 ? red[t - 1] : 0.0;
+    unsigned long long first = ~0ull;
+    for (int k = k0; k < k1; ++k) {
+      run += psd[k];
+      if (run > thr && first == ~0ull) first = (unsigned long long)k;
+    }
+    const unsigned long long kc = block_min_u64(first, red);
     if (t == 0) {
       const double ratio = total > 0 ? low / total : 0.0;
       c.hpf_on = ratio > 0.2;
       double cutoff = 80.0;
-      if (c.hpf_on) {
-        double cum = 0;
-        for (int k = 0; k < NB; ++k) cum += psd[k];
-        const double thr = 0.1 * cum;
-        double run = 0;
-        for (int k = 0; k < NB; ++k) {
-          run += psd[k];
-          if (run > thr) {
-            cutoff = fmax(80.0, fmin(100.0, k * df));
-            break;
-          }
-        }
-      }
+      if (c.hpf_on && kc != ~0ull) cutoff = fmax(80.0, fmin(100.0, (double)kc * df));
       c.hpf_cutoff = c.hpf_on ? cutoff : 0.0;
     }
   } else {                                       // ref :175-203
     double lo = 0, mid = 0, hi = 0;
-    for (int k = t; k < NB; k += FE_T) {
+    for (int k = t; k < NB; k += FE_C) {
       const double f = k * df;
       if (f < 500.0) lo += psd[k];
       else if (f < 2000.0) mid += psd[k];
@@ -342,100 +398,121 @@ __global__ __launch_bounds__(FE_T) void fe_welch_kernel(const double* __restrict
 
 // ---- zero-phase IIR filtering of a clip in place (scipy.signal.filtfilt: odd extension by 3 * taps samples, initial
 // state = steady state of the first sample, forward then backward) -------------------------------------------------------
-struct Iir {
-  double b[5], a[5];
+// The transfer function is run as a cascade of second-order sections in direct form II transposed, not as scipy's
+// single fourth-order recurrence: the same linear operator, but a parallel evaluation has to carry filter states across
+// chunk boundaries, and the fourth-order companion states of a Butterworth high-pass at 80-100 Hz / 16 kHz (four poles
+// within 0.04 of z = 1) amplify a rounding error in a carried state by ~1e5 (its powers reach 1e3 per 16 samples),
+// which put a two-level state chain 4e-5 away from scipy.  Biquad states amplify by < 1e2; this form agrees with
+// scipy.signal.filtfilt to 7e-11 on the fixture clips (numpy emulation of this schedule), i.e. at scipy's own rounding level.
+//
+// Schedule: the extended clip is processed in tiles of FE_IIR_T x FE_SUB samples held in LDS (coalesced global reads and
+// writes, the next tile's reads in flight while this one is filtered); inside a tile every thread owns FE_SUB consecutive
+// samples.  Per section: (1) every thread runs its samples from the zero state -> fin_t; (2) the start states
+// s_{t+1} = P s_t + fin_t (P = A^FE_SUB) come from a scan with the uniform matrix P: inside a wave a Hillis-Steele scan
+// e_t += P^d e_{t-d} (d = 1..32, shuffles), across the waves W_{w+1} = P^64 W_w + E_w from the state carried out of the
+// previous tile, and s_t = P^lane W_w + e_{t-1}; (3) every thread re-runs its samples from s_t, in place.
+constexpr int FE_SUB = 16;                              // samples per thread and tile
+constexpr int FE_TILE = FE_IIR_T * FE_SUB;              // 8192
+constexpr int FE_LDS_STRIDE = FE_SUB + 1;               // odd stride in doubles: the lanes of a wave hit different banks
+
+struct Biquad {
+  double b0, b1, b2, a1, a2;
 };
-SER_DEVFN void iir_step(const Iir& f, double x, double* z, double& y) {       // direct form II transposed, as lfilter
-  y = f.b[0] * x + z[0];
-  z[0] = z[1] + f.b[1] * x - f.a[1] * y;
-  z[1] = z[2] + f.b[2] * x - f.a[2] * y;
-  z[2] = z[3] + f.b[3] * x - f.a[3] * y;
-  z[3] = f.b[4] * x - f.a[4] * y;
+struct Cascade {
+  int n, padlen;
+  Biquad s[2];
+};
+SER_DEVFN void bq_step(const Biquad& f, double x, double& z0, double& z1, double& y) {
+  y = f.b0 * x + z0;
+  z0 = z1 + f.b1 * x - f.a1 * y;
+  z1 = f.b2 * x - f.a2 * y;
 }
-// scipy.signal.iirnotch(w0, Q, fs)
-SER_DEVFN void design_notch(double hz, double q, double fs, Iir& f) {
+// scipy.signal.iirnotch(w0, Q, fs): one section
+SER_DEVFN void design_notch(double hz, double q, double fs, Cascade& c) {
   const double w0 = hz / (fs / 2) * M_PI, bw = w0 / q;
   const double beta = tan(bw / 2.0);                       // sqrt(1 - gb^2) / gb = 1 for gb = 1/sqrt(2)
   const double gain = 1.0 / (1.0 + beta);
-  f.b[0] = gain; f.b[1] = -2.0 * cos(w0) * gain; f.b[2] = gain; f.b[3] = f.b[4] = 0;
-  f.a[0] = 1.0; f.a[1] = -2.0 * gain * cos(w0); f.a[2] = 2.0 * gain - 1.0; f.a[3] = f.a[4] = 0;
+  c.n = 1;
+  c.padlen = 9;                                            // 3 * max(len(a), len(b))
+  c.s[0] = Biquad{gain, -2.0 * cos(w0) * gain, gain, -2.0 * gain * cos(w0), 2.0 * gain - 1.0};
 }
-// scipy.signal.butter(4, wn, 'high'): analog prototype -> lp2hp -> bilinear (fs = 2) -> polynomial coefficients
-SER_DEVFN void design_highpass4(double wn, Iir& f) {
+// scipy.signal.butter(4, wn, 'high') (analog prototype -> lp2hp -> bilinear with fs = 2) with its four poles paired into
+// two sections, numerator (1 - z^-1)^2 each, the gain in the first
+SER_DEVFN void design_highpass4(double wn, Cascade& c) {
   const double warped = 4.0 * tan(M_PI * wn / 2.0);
-  double pr[4], pi[4];
-  for (int m = 0; m < 4; ++m) {                            // buttap: p = -exp(i pi k / 8), k = -3, -1, 1, 3
-    const double ang = M_PI * (2 * m - 3) / 8.0;
-    const double ar = -cos(ang), ai = -sin(ang);
-    const double den = ar * ar + ai * ai;                  // lp2hp: p -> warped / p
-    const double hr = warped * ar / den, hi = -warped * ai / den;
-    const double nr = 4.0 + hr, ni = hi, dr = 4.0 - hr, di = -hi, dd = dr * dr + di * di;   // bilinear: (4 + p) / (4 - p)
-    pr[m] = (nr * dr + ni * di) / dd;
-    pi[m] = (ni * dr - nr * di) / dd;
-  }
-  // gain: k = real(prod(4 - 0) / prod(4 - p_hp)) with four zeros at the origin -> 4^4 / prod(4 - p_hp)
-  double gr = 1, gi = 0;
+  double gr = 1, gi = 0;                                   // prod(4 - p_hp) over all four poles
   for (int m = 0; m < 4; ++m) {
-    const double ang = M_PI * (2 * m - 3) / 8.0;
+    const double ang = M_PI * (2 * m - 3) / 8.0;           // buttap: p = -exp(i pi k / 8), k = -3, -1, 1, 3
     const double ar = -cos(ang), ai = -sin(ang), den = ar * ar + ai * ai;
-    const double dr = 4.0 - warped * ar / den, di = warped * ai / den;
+    const double hr = warped * ar / den, hi = -warped * ai / den;        // lp2hp: p -> warped / p
+    const double dr = 4.0 - hr, di = -hi;
     const double tr = gr * dr - gi * di, ti = gr * di + gi * dr;
     gr = tr; gi = ti;
-  }
-  const double k = 256.0 * gr / (gr * gr + gi * gi);       // real part of 256 / (gr + i gi)
-  double cr[5] = {1, 0, 0, 0, 0}, ci[5] = {0, 0, 0, 0, 0};    // poly(p): multiply out (x - p_m)
-  for (int m = 0; m < 4; ++m) {
-    for (int j = m + 1; j >= 1; --j) {
-      const double tr = cr[j] - (pr[m] * cr[j - 1] - pi[m] * ci[j - 1]);
-      const double ti = ci[j] - (pr[m] * ci[j - 1] + pi[m] * cr[j - 1]);
-      cr[j] = tr; ci[j] = ti;
+    if (m < 2) {                                           // k = -3 and k = -1; their conjugates are k = 3 and k = 1
+      const double nr = 4.0 + hr, ni = hi, dd = dr * dr + di * di;       // bilinear: (4 + p) / (4 - p)
+      const double pr = (nr * dr + ni * di) / dd, pi = (ni * dr - nr * di) / dd;
+      c.s[m] = Biquad{1.0, -2.0, 1.0, -2.0 * pr, pr * pr + pi * pi};
     }
   }
-  const double bz[5] = {1, -4, 6, -4, 1};
-  for (int j = 0; j < 5; ++j) { f.b[j] = k * bz[j]; f.a[j] = cr[j]; }
+  const double k = 256.0 * gr / (gr * gr + gi * gi);       // real(4^4 / prod(4 - p_hp)): four zeros at the origin
+  c.s[0].b0 *= k; c.s[0].b1 *= k; c.s[0].b2 *= k;
+  c.n = 2;
+  c.padlen = 15;
+}
+
+SER_DEVFN void m2_apply(const double* M /*[4] row-major*/, double& v0, double& v1) {
+  const double n0 = M[0] * v0 + M[1] * v1, n1 = M[2] * v0 + M[3] * v1;
+  v0 = n0;
+  v1 = n1;
 }
 
 __global__ __launch_bounds__(FE_IIR_T) void fe_filtfilt_kernel(double* __restrict__ xs, int T, int which, double fs,
                                                                 CondState* __restrict__ st, double* __restrict__ tmp, int tmp_stride) {
-  __shared__ Iir F;
-  __shared__ double zi[4], Ap[4][4];
-  __shared__ double fin[FE_IIR_T][4], start[FE_IIR_T][4];
-  const int b = blockIdx.x, t = threadIdx.x;
+  constexpr int NW = FE_IIR_T / 64;
+  __shared__ Cascade F;
+  __shared__ double zi[2][2], dc[2];
+  __shared__ double Pw[2][7][4];                  // per section: P^(2^j), j = 0..6, P = A^FE_SUB (row-major 2 x 2)
+  __shared__ double carry[2][2][2];               // [tile parity][section][state]
+  __shared__ double Ew[2][NW][2];                 // per section: zero-state response across each wave
+  __shared__ double buf[FE_IIR_T * FE_LDS_STRIDE];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const CondState& c = st[b];
   if (which == 0 ? !c.hum50 : (which == 1 ? !c.hum60 : !c.hpf_on)) return;
   double* x = xs + (long long)b * T;
   double* y1 = tmp + (long long)b * tmp_stride;
-  const int padlen = which == 2 ? 15 : 9;                 // 3 * max(len(a), len(b))
-  const int L = T + 2 * padlen, Lc = (L + FE_IIR_T - 1) / FE_IIR_T, nch = (L + Lc - 1) / Lc;
   if (t == 0) {
     if (which == 2) design_highpass4(c.hpf_cutoff / (fs / 2), F);
     else design_notch(which == 0 ? 50.0 : 60.0, 30.0, fs, F);
-    // lfilter_zi: (I - A) zi = B, A = companion(a)^T, B = b[1:] - a[1:] b[0]
-    double M[4][5];
-    for (int i = 0; i < 4; ++i) {
-      for (int j = 0; j < 4; ++j) M[i][j] = (i == j ? 1.0 : 0.0) - ((j == 0 ? -F.a[i + 1] : 0.0) + (j == i + 1 ? 1.0 : 0.0));
-      M[i][4] = F.b[i + 1] - F.a[i + 1] * F.b[0];
+    for (int s = 0; s < F.n; ++s) {
+      // steady state for a unit step (scipy lfilter_zi / sosfilt_zi): (I - A) zi = B, A = [[-a1, 1], [-a2, 0]],
+      // B = [b1 - a1 b0, b2 - a2 b0]; the next section sees the step scaled by this one's DC gain
+      const Biquad& q = F.s[s];
+      const double B0 = q.b1 - q.a1 * q.b0, B1 = q.b2 - q.a2 * q.b0;
+      const double det = (1.0 + q.a1) + q.a2;              // det [[1 + a1, -1], [a2, 1]]
+      zi[s][0] = (B0 + B1) / det;
+      zi[s][1] = ((1.0 + q.a1) * B1 - q.a2 * B0) / det;
+      dc[s] = (q.b0 + q.b1 + q.b2) / det;
     }
-    for (int col = 0; col < 4; ++col) {
-      int piv = col;
-      for (int r = col + 1; r < 4; ++r)
-        if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
-      for (int j = 0; j < 5; ++j) { const double tt = M[col][j]; M[col][j] = M[piv][j]; M[piv][j] = tt; }
-      for (int r = 0; r < 4; ++r) {
-        if (r == col) continue;
-        const double m = M[r][col] / M[col][col];
-        for (int j = col; j < 5; ++j) M[r][j] -= m * M[col][j];
-      }
-    }
-    for (int i = 0; i < 4; ++i) zi[i] = M[i][4] / M[i][i];
   }
   __syncthreads();
-  const Iir f = F;
-  if (t < 4) {            // column t of A^Lc: Lc zero-input steps from the unit state e_t
-    double z[4] = {0, 0, 0, 0}, y;
-    z[t] = 1.0;
-    for (int i = 0; i < Lc; ++i) iir_step(f, 0.0, z, y);
-    for (int i = 0; i < 4; ++i) Ap[i][t] = z[i];
+  const Cascade f = F;
+  const int padlen = f.padlen, L = T + 2 * padlen;
+  if (t < 2 * f.n) {       // column (t & 1) of P = A^FE_SUB of section t >> 1: FE_SUB zero-input steps from a unit state
+    const int s = t >> 1, col = t & 1;
+    double z0 = col == 0 ? 1.0 : 0.0, z1 = col == 1 ? 1.0 : 0.0, y;
+    for (int i = 0; i < FE_SUB; ++i) bq_step(f.s[s], 0.0, z0, z1, y);
+    Pw[s][0][col] = z0;
+    Pw[s][0][2 + col] = z1;
+  }
+  __syncthreads();
+  if (t < f.n) {           // P^2, P^4, ..., P^64 by squaring
+    for (int j = 1; j < 7; ++j) {
+      const double* m = Pw[t][j - 1];
+      Pw[t][j][0] = m[0] * m[0] + m[1] * m[2];
+      Pw[t][j][1] = m[0] * m[1] + m[1] * m[3];
+      Pw[t][j][2] = m[2] * m[0] + m[3] * m[2];
+      Pw[t][j][3] = m[2] * m[1] + m[3] * m[3];
+    }
   }
   const double x0 = x[0], xl = x[T - 1];
   auto ext = [&](int i) -> double {                        // scipy odd_ext
@@ -443,41 +520,87 @@ __global__ __launch_bounds__(FE_IIR_T) void fe_filtfilt_kernel(double* __restric
     if (i < padlen + T) return x[i - padlen];
     return 2.0 * xl - x[T - 2 - (i - padlen - T)];
   };
+  double* mine = buf + t * FE_LDS_STRIDE;
   for (int pass = 0; pass < 2; ++pass) {
-    auto in = [&](int i) -> double { return pass == 0 ? ext(i) : y1[L - 1 - i]; };
-    const int i0 = t * Lc, i1 = min(L, i0 + Lc);
-    {                      // chunk response from the zero state
-      double z[4] = {0, 0, 0, 0}, y;
-      for (int i = i0; i < i1; ++i) iir_step(f, in(i), z, y);
-      for (int j = 0; j < 4; ++j) fin[t][j] = z[j];
-    }
+    auto in = [&](int i) -> double { return i < L ? (pass == 0 ? ext(i) : y1[L - 1 - i]) : 0.0; };
     __syncthreads();
-    if (t == 0) {          // chain the chunk start states: s_{c+1} = A^Lc s_c + fin_c
-      const double first = in(0);
-      double s[4];
-      for (int j = 0; j < 4; ++j) s[j] = zi[j] * first;
-      for (int cidx = 0; cidx < nch; ++cidx) {
-        for (int j = 0; j < 4; ++j) start[cidx][j] = s[j];
-        double n[4];
-        for (int i = 0; i < 4; ++i) n[i] = Ap[i][0] * s[0] + Ap[i][1] * s[1] + Ap[i][2] * s[2] + Ap[i][3] * s[3] + fin[cidx][i];
-        for (int j = 0; j < 4; ++j) s[j] = n[j];
+    if (t == 0) {
+      double first = in(0);
+      for (int s = 0; s < f.n; ++s) {
+        carry[0][s][0] = zi[s][0] * first;
+        carry[0][s][1] = zi[s][1] * first;
+        first *= dc[s];
       }
     }
-    __syncthreads();
-    if (i0 < L) {
-      double z[4] = {start[t][0], start[t][1], start[t][2], start[t][3]}, y;
-      if (pass == 0) {
-        // the forward output may not overwrite x yet (ext() of other chunks still reads it): it goes to y1
-        for (int i = i0; i < i1; ++i) { iir_step(f, in(i), z, y); y1[i] = y; }
-      } else {
-        for (int i = i0; i < i1; ++i) {
-          iir_step(f, in(i), z, y);
-          const int tt = L - 1 - i - padlen;              // result = reversed backward output without the padding
+    double nx[FE_SUB];
+#pragma unroll
+    for (int k = 0; k < FE_SUB; ++k) nx[k] = in(t + k * FE_IIR_T);
+    int par = 0;
+    for (int t0 = 0; t0 < L; t0 += FE_TILE, par ^= 1) {
+      const int n = min(FE_TILE, L - t0);
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < FE_SUB; ++k) {
+        const int i = t + k * FE_IIR_T;
+        buf[(i / FE_SUB) * FE_LDS_STRIDE + (i % FE_SUB)] = nx[k];
+      }
+      __syncthreads();
+      if (t0 + FE_TILE < L) {
+#pragma unroll
+        for (int k = 0; k < FE_SUB; ++k) nx[k] = in(t0 + FE_TILE + t + k * FE_IIR_T);
+      }
+      const int cnt = max(0, min(FE_SUB, n - t * FE_SUB));           // my samples in this tile
+      const int last = (n - 1) / FE_SUB;                             // the thread that holds the tile's last sample
+      double xr[FE_SUB];
+#pragma unroll
+      for (int i = 0; i < FE_SUB; ++i) xr[i] = mine[i];
+      for (int s = 0; s < f.n; ++s) {
+        const Biquad q = f.s[s];
+        double e0 = 0, e1 = 0, y;
+#pragma unroll
+        for (int i = 0; i < FE_SUB; ++i)
+          if (i < cnt) bq_step(q, xr[i], e0, e1, y);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                                // e_t = sum_{i <= t} P^(t - i) fin_i inside the wave
+          double u0 = __shfl_up(e0, 1u << j, 64), u1 = __shfl_up(e1, 1u << j, 64);
+          m2_apply(Pw[s][j], u0, u1);
+          if (lane >= (1 << j)) { e0 += u0; e1 += u1; }
+        }
+        if (lane == 63) { Ew[s][wave][0] = e0; Ew[s][wave][1] = e1; }
+        double p0 = __shfl_up(e0, 1, 64), p1 = __shfl_up(e1, 1, 64);
+        if (lane == 0) p0 = p1 = 0.0;
+        __syncthreads();
+        double w0 = carry[par][s][0], w1 = carry[par][s][1];         // state at the start of my wave
+        for (int w = 0; w < wave; ++w) {
+          m2_apply(Pw[s][6], w0, w1);
+          w0 += Ew[s][w][0];
+          w1 += Ew[s][w][1];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if ((lane >> j) & 1) m2_apply(Pw[s][j], w0, w1);           // P^lane
+        double z0 = w0 + p0, z1 = w1 + p1;
+#pragma unroll
+        for (int i = 0; i < FE_SUB; ++i)
+          if (i < cnt) { bq_step(q, xr[i], z0, z1, y); xr[i] = y; }
+        if (t == last) {                                              // the true state after the tile's last sample
+          carry[par ^ 1][s][0] = z0;
+          carry[par ^ 1][s][1] = z1;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < FE_SUB; ++i) mine[i] = xr[i];
+      __syncthreads();
+      for (int i = t; i < n; i += FE_IIR_T) {
+        const double y = buf[(i / FE_SUB) * FE_LDS_STRIDE + (i % FE_SUB)];
+        const int gi = t0 + i;
+        if (pass == 0) y1[gi] = y;                         // x is still read by ext() of later tiles: forward output -> y1
+        else {
+          const int tt = L - 1 - gi - padlen;              // result = reversed backward output without the padding
           if (tt >= 0 && tt < T) x[tt] = y;
         }
       }
     }
-    __syncthreads();
   }
 }
 
@@ -499,16 +622,15 @@ __global__ void fe_load_kernel(const float* __restrict__ wave, const int* __rest
 }
 
 // ---- energy-ratio SNR (ref audio_conditioning.py:161-173): 10 log10(mean x^2 / 10th percentile of x^2), in [0, 50] ------
-__global__ __launch_bounds__(FE_T) void fe_snr_kernel(const double* __restrict__ xs, int T, int after, CondState* __restrict__ st) {
-  __shared__ double red[FE_T];
-  __shared__ unsigned hist[256];
-  __shared__ unsigned long long bc[2];
+__global__ __launch_bounds__(FE_C) void fe_snr_kernel(const double* __restrict__ xs, int T, int after, CondState* __restrict__ st) {
+  __shared__ double red[FE_C];
+  __shared__ SelectLds sel;
   const int b = blockIdx.x;
   const double* x = xs + (long long)b * T;
   double s = 0;
-  for (int i = threadIdx.x; i < T; i += FE_T) s += x[i] * x[i];
+  for (int i = threadIdx.x; i < T; i += FE_C) s += x[i] * x[i];
   const double e = block_sum(s, red) / T;
-  const double floor_ = block_percentile([&](int i) { return x[i] * x[i]; }, T, 10.0, hist, red, bc);
+  const double floor_ = block_percentile([&](int i) { return x[i] * x[i]; }, T, 10.0, sel, red);
   if (threadIdx.x == 0) {
     double snr = floor_ > 0 ? 10.0 * log10(e / floor_) : 50.0;
     snr = fmax(0.0, fmin(50.0, snr));
@@ -579,22 +701,22 @@ __global__ __launch_bounds__(FE_IIR_T) void fe_wiener_kernel(double* __restrict_
 // The reference's T60 is where(cumsum(decay^2) < 0.001 total)[0][0] / sr: the running sum never decreases, so that index is
 // 0 (when the peak sample alone is below -30 dB of the tail energy) or missing (-> 0.1 s).  Both are below the 0.5 s
 // threshold, so its `simple_dereverb` never runs and feature 3 is always 0.
-__global__ __launch_bounds__(FE_T) void fe_finish_kernel(const double* __restrict__ xs, int T, double fs, CondState* __restrict__ st,
+__global__ __launch_bounds__(FE_C) void fe_finish_kernel(const double* __restrict__ xs, int T, double fs, CondState* __restrict__ st,
                                                           float* __restrict__ out, float* __restrict__ raw, float* __restrict__ meta) {
-  __shared__ double red[FE_T];
+  __shared__ double red[FE_C];
   const int b = blockIdx.x, t = threadIdx.x;
   const double* x = xs + (long long)b * T;
   CondState& c = st[b];
   double mx = 0, s2 = 0;
-  for (int i = t; i < T; i += FE_T) { mx = fmax(mx, fabs(x[i])); s2 += x[i] * x[i]; }
+  for (int i = t; i < T; i += FE_C) { mx = fmax(mx, fabs(x[i])); s2 += x[i] * x[i]; }
   const double peak = block_max(mx, red);
   const double ms = block_sum(s2, red) / T;
   unsigned long long first = ~0ull;                         // np.argmax: first index of the maximum
-  for (int i = t; i < T; i += FE_T)
+  for (int i = t; i < T; i += FE_C)
     if (fabs(x[i]) == peak) { first = (unsigned long long)i; break; }
   const int p = (int)block_min_u64(first, red);
   double tail = 0;
-  for (int i = p + t; i < T; i += FE_T) tail += x[i] * x[i];
+  for (int i = p + t; i < T; i += FE_C) tail += x[i] * x[i];
   tail = block_sum(tail, red);
   double t60 = 0.1;
   if ((double)(T - p) >= fs && tail != 0.0 && x[p] * x[p] < tail * 0.001) t60 = 0.0;
@@ -606,7 +728,7 @@ __global__ __launch_bounds__(FE_T) void fe_finish_kernel(const double* __restric
   const double adj = fmax(-6.0, fmin(6.0, -23.0 - lufs));
   const double g = pow(10.0, adj / 20.0);
   double mo = 0;
-  for (int i = t; i < T; i += FE_T) {
+  for (int i = t; i < T; i += FE_C) {
     double v = x[i];
     if (comp && fabs(v) > thr) v = copysign(thr + (fabs(v) - thr) / ratio, v);
     v *= g;
@@ -659,25 +781,24 @@ __global__ __launch_bounds__(FE_T) void fe_rms_kernel(const float* __restrict__ 
 // energy VAD (ref quality_gates.py:111-137): speech = rms > 30th percentile + 0.1 std, 5-tap median (scipy.ndimage
 // 'reflect' boundary), speech_prob = mean
 constexpr int FE_MAX_VAD_FRAMES = 16384;
-__global__ __launch_bounds__(FE_T) void fe_vad_kernel(const float* __restrict__ energy, int nfr, double* __restrict__ speech_prob) {
-  __shared__ double red[FE_T];
-  __shared__ unsigned hist[256];
-  __shared__ unsigned long long bc[2];
+__global__ __launch_bounds__(FE_C) void fe_vad_kernel(const float* __restrict__ energy, int nfr, double* __restrict__ speech_prob) {
+  __shared__ double red[FE_C];
+  __shared__ SelectLds sel;
   __shared__ unsigned char sp[FE_MAX_VAD_FRAMES];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* e = energy + (long long)b * nfr;
   double s = 0;
-  for (int i = t; i < nfr; i += FE_T) s += e[i];
+  for (int i = t; i < nfr; i += FE_C) s += e[i];
   const double mean = block_sum(s, red) / nfr;
   double dv = 0;
-  for (int i = t; i < nfr; i += FE_T) dv += (e[i] - mean) * (e[i] - mean);
+  for (int i = t; i < nfr; i += FE_C) dv += (e[i] - mean) * (e[i] - mean);
   const double sd = sqrt(block_sum(dv, red) / nfr);
-  const double p30 = block_percentile([&](int i) { return (double)e[i]; }, nfr, 30.0, hist, red, bc);
+  const double p30 = block_percentile([&](int i) { return (double)e[i]; }, nfr, 30.0, sel, red);
   const double thr = p30 + 0.1 * sd;
-  for (int i = t; i < nfr; i += FE_T) sp[i] = (double)e[i] > thr;
+  for (int i = t; i < nfr; i += FE_C) sp[i] = (double)e[i] > thr;
   __syncthreads();
   double cnt = 0;
-  for (int i = t; i < nfr; i += FE_T) {
+  for (int i = t; i < nfr; i += FE_C) {
     int on = 0;
     for (int d = -2; d <= 2; ++d) {
       int j = i + d;
@@ -694,19 +815,19 @@ __global__ __launch_bounds__(FE_T) void fe_vad_kernel(const float* __restrict__ 
 
 // SNR from the STFT magnitudes, clipping, spectral naturalness, music / laughter scores, the abstain policy, the quality
 // score and the 8 features (ref :189-247, :320-403, :497-560)
-__global__ __launch_bounds__(FE_T) void fe_quality_kernel(const float* __restrict__ wave, int T, const float* __restrict__ mags,
+__global__ __launch_bounds__(FE_C) void fe_quality_kernel(const float* __restrict__ wave, int T, const float* __restrict__ mags,
                                                            const double* __restrict__ descs, int F, int nf,
                                                            const float* __restrict__ rms_long, int nfr_long,
                                                            const double* __restrict__ speech_prob, const float* __restrict__ lid,
                                                            float* __restrict__ raw, float* __restrict__ metrics, int* __restrict__ decision) {
-  __shared__ double red[FE_T];
+  __shared__ double red[FE_C];
   const int b = blockIdx.x, t = threadIdx.x, NB = NFFT / 2 + 1;
   const float* x = wave + (long long)b * T;
   float mx = 0.f;
-  for (int i = t; i < T; i += FE_T) mx = fmaxf(mx, fabsf(x[i]));
+  for (int i = t; i < T; i += FE_C) mx = fmaxf(mx, fabsf(x[i]));
   mx = (float)block_max((double)mx, red);
   double cnt = 0;
-  for (int i = t; i < T; i += FE_T) {
+  for (int i = t; i < T; i += FE_C) {
     const float v = mx > 0.f ? __fdiv_rn(x[i], mx) : x[i];        // float32 division, as numpy does on the float32 clip
     cnt += fabsf(v) > 0.95f;
   }
@@ -715,7 +836,7 @@ __global__ __launch_bounds__(FE_T) void fe_quality_kernel(const float* __restric
   if (nf > 0) {
     const float* m = mags + (long long)b * F * NB;
     double sp = 0, np_ = 0;
-    for (int k = t; k < NB; k += FE_T) {
+    for (int k = t; k < NB; k += FE_C) {
       double sg = 0, no = 0;
       for (int f = nf; f < F - nf; ++f) sg += m[(long long)f * NB + k];
       for (int f = F - nf; f < F; ++f) no += m[(long long)f * NB + k];
@@ -731,14 +852,14 @@ __global__ __launch_bounds__(FE_T) void fe_quality_kernel(const float* __restric
   }
   const double* d = descs + (long long)b * F * 3;
   double c0 = 0, c1 = 0, c2 = 0;
-  for (int f = t; f < F; f += FE_T) { c0 += d[f * 3]; c1 += d[f * 3 + 1]; c2 += d[f * 3 + 2]; }
+  for (int f = t; f < F; f += FE_C) { c0 += d[f * 3]; c1 += d[f * 3 + 1]; c2 += d[f * 3 + 2]; }
   const double cen = block_sum(c0, red) / F, bw = block_sum(c1, red) / F, roll = block_sum(c2, red) / F;
   const float* rl = rms_long + (long long)b * nfr_long;
   double s = 0;
-  for (int i = t; i < nfr_long; i += FE_T) s += rl[i];
+  for (int i = t; i < nfr_long; i += FE_C) s += rl[i];
   const double rmean = block_sum(s, red) / nfr_long;
   double dv = 0;
-  for (int i = t; i < nfr_long; i += FE_T) dv += (rl[i] - rmean) * (rl[i] - rmean);
+  for (int i = t; i < nfr_long; i += FE_C) dv += (rl[i] - rmean) * (rl[i] - rmean);
   const double rvar = block_sum(dv, red) / nfr_long;
   if (t == 0) {
     auto clip01 = [](double v) { return fmax(0.0, fmin(1.0, v)); };
@@ -833,11 +954,11 @@ extern "C" int ser_quality_gates(const float* wave, int B, int T, int sample_rat
                      (int)(fs * 0.010), pad_reflect, l.nfr_vad, l.rms_vad);
   hipLaunchKernelGGL(fe_rms_kernel, dim3(ceil_div(l.nfr_long, FE_T / 64), B), dim3(FE_T), 0, st, wave, T, 2048, 512, pad_reflect,
                      l.nfr_long, l.rms_long);
-  hipLaunchKernelGGL(fe_vad_kernel, dim3(B), dim3(FE_T), 0, st, l.rms_vad, l.nfr_vad, l.speech);
+  hipLaunchKernelGGL(fe_vad_kernel, dim3(B), dim3(FE_C), 0, st, l.rms_vad, l.nfr_vad, l.speech);
   hipLaunchKernelGGL(fe_fft_kernel<2048>, dim3(l.F, B), dim3(FE_T), 0, st, (const void*)wave, 0, (long long)T, T, 512, 1024,
                      pad_reflect, 0, l.F, fs, tab, (double*)nullptr, l.mag, l.desc);
   const int nf = (int)(0.1 * (double)l.F);
-  hipLaunchKernelGGL(fe_quality_kernel, dim3(B), dim3(FE_T), 0, st, wave, T, l.mag, l.desc, l.F, nf, l.rms_long, l.nfr_long,
+  hipLaunchKernelGGL(fe_quality_kernel, dim3(B), dim3(FE_C), 0, st, wave, T, l.mag, l.desc, l.F, nf, l.rms_long, l.nfr_long,
                      l.speech, lid, q_raw, q_metrics, decision);
   SER_LAUNCH_CHECK();
   return SER_OK;
@@ -865,19 +986,19 @@ extern "C" int ser_audio_conditioning(const float* wave, const int* decision, in
     else
       hipLaunchKernelGGL(fe_fft_kernel<1024>, dim3(nseg, B), dim3(FE_T), 0, st, (const void*)l.x, 1, (long long)T, T, 512, 0, 0, 1,
                          nseg, fs, tab, l.power, (float*)nullptr, (double*)nullptr);
-    hipLaunchKernelGGL(fe_welch_kernel, dim3(B), dim3(FE_T), 0, st, l.power, nseg, N, fs, tab, mode, l.st);
+    hipLaunchKernelGGL(fe_welch_kernel, dim3(B), dim3(FE_C), 0, st, l.power, nseg, N, fs, tab, mode, l.st);
   };
   welch(2048, l.nseg2048, WELCH_HUM);                                   // 1. hum notch
   for (int which = 0; which < 2; ++which)
     hipLaunchKernelGGL(fe_filtfilt_kernel, dim3(B), dim3(FE_IIR_T), 0, st, l.x, T, which, fs, l.st, l.tmp, l.tmp_stride);
   welch(2048, l.nseg2048, WELCH_HPF);                                   // 2. high-pass
   hipLaunchKernelGGL(fe_filtfilt_kernel, dim3(B), dim3(FE_IIR_T), 0, st, l.x, T, 2, fs, l.st, l.tmp, l.tmp_stride);
-  hipLaunchKernelGGL(fe_snr_kernel, dim3(B), dim3(FE_T), 0, st, l.x, T, 0, l.st);   // 3. adaptive denoise
+  hipLaunchKernelGGL(fe_snr_kernel, dim3(B), dim3(FE_C), 0, st, l.x, T, 0, l.st);   // 3. adaptive denoise
   welch(1024, l.nseg1024, WELCH_NOISE);
   const int M = 2 * (int)(0.1 * (double)T);
   hipLaunchKernelGGL(fe_wiener_kernel, dim3(B), dim3(FE_IIR_T), 0, st, l.x, T, M, l.st, l.P1, l.P2);
-  hipLaunchKernelGGL(fe_snr_kernel, dim3(B), dim3(FE_T), 0, st, l.x, T, 1, l.st);
-  hipLaunchKernelGGL(fe_finish_kernel, dim3(B), dim3(FE_T), 0, st, l.x, T, fs, l.st, out, c_raw, c_meta);   // 4./5. + features
+  hipLaunchKernelGGL(fe_snr_kernel, dim3(B), dim3(FE_C), 0, st, l.x, T, 1, l.st);
+  hipLaunchKernelGGL(fe_finish_kernel, dim3(B), dim3(FE_C), 0, st, l.x, T, fs, l.st, out, c_raw, c_meta);   // 4./5. + features
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

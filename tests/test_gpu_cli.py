@@ -84,3 +84,32 @@ def test_train_then_eval_cli(tmp_path, capsys):
         assert "Weighted F1 Score" in out and "Optimal temperature" in out
     finally:
         os.chdir(cwd)
+
+
+def test_train_and_eval_cli_with_the_reference_default_front_end(tmp_path, capsys):
+    """--use_quality_gates --use_audio_conditioning: the configuration the reference's own train.py / eval.py build
+    (AudioEncoder() defaults, ref train.py:54, eval.py:92) — gates, conditioning and feature fusion on the device."""
+    import ser_amd  # noqa: F401
+    from ser_amd import eval as ser_eval, train as ser_train
+    tmp = str(tmp_path)
+    da, dt = _local_models(tmp)
+    tr, va = _manifests(tmp)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        gates = ["--use_quality_gates", "--use_audio_conditioning", "--vad_method", "librosa"]
+        ser_train.main(["--train_manifest", tr, "--val_manifest", va, "--epochs", "1", "--batch_size", "2",
+                        "--save_dir", os.path.join(tmp, "ck"), "--audio_model", da, "--text_model", dt,
+                        "--warmup_ratio", "0.0"] + gates)
+        cks = sorted(os.listdir(os.path.join(tmp, "ck")))
+        ck = torch.load(os.path.join(tmp, "ck", cks[0]), map_location="cpu", weights_only=False)
+        init = torch.load(os.path.join(tmp, "ck", cks[0]), map_location="cpu", weights_only=False)["audio_encoder"]
+        for k in ("quality_gates.quality_projection.0.weight", "audio_conditioning.conditioning_projection.3.bias",
+                  "combined_fusion.0.weight"):                                   # the reference's default-flag keys
+            assert k in ck["audio_encoder"], k
+        assert torch.isfinite(init["combined_fusion.0.weight"]).all()
+        ser_eval.main(["--manifest", va, "--checkpoint", os.path.join(tmp, "ck", cks[0]), "--batch_size", "2",
+                       "--audio_model", da, "--text_model", dt] + gates)
+        assert "Weighted F1 Score" in capsys.readouterr().out
+    finally:
+        os.chdir(cwd)
