@@ -21,12 +21,17 @@ def golden_dir():
 @pytest.fixture(autouse=True)
 def _library_defaults(request):
     """Process-wide library settings back to their defaults before every GPU test (a system built in `bf16` mode sets
-    the backward head products to 1; module-level parity tests expect the 3-product default)."""
+    the backward head products to 1; module-level parity tests expect the 3-product default), and the dropout-site counter
+    back to zero: a layer's mask is keyed by its process-unique site id, so without the reset the masks a test draws - and
+    with them which ReLU units sit next to a kink in the finite-difference / float64 comparisons - depend on how many
+    modules earlier tests built."""
     if request.node.get_closest_marker("gpu") is not None:
         try:
             import ser_amd  # noqa: F401
             from ser_amd import _lib as L
             L.lib.ser_set_head_backward_products(3)
+            from ser_amd import _ops
+            _ops._SITES[0] = 0
         except Exception:   # noqa: BLE001 - the library is absent on the CPU-only box; GPU tests are deselected there
             pass
     yield

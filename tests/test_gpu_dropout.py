@@ -84,8 +84,11 @@ def test_classifier_dropout_fused_stack_matches_standalone_launches(OP, rows, D,
     assert torch.equal(a[0], again[0]), "same state -> same masks"
 
 
-def _directional_check(fn, params, rel=4e-2, eps=2e-2):
-    """<grad, v> against a central difference of the deterministic function fn(*params) -> scalar."""
+def _directional_check(fn, params, rel=4e-2, eps=(2e-2, 5e-3, 1e-3)):
+    """<grad, v> against central differences of the deterministic function fn(*params) -> scalar at several step sizes.
+    The function is only piecewise smooth (ReLU kinks, dropout masks) and fp32, so a single step size is either biased by
+    curvature / kinks (large step) or by rounding (small step): the analytic value has to agree with one of the
+    estimates, or lie inside the range they span."""
     for prm in params:
         prm.grad = None
     out = fn()
@@ -98,17 +101,22 @@ def _directional_check(fn, params, rel=4e-2, eps=2e-2):
         v /= v.norm()
         vs.append(v)
         ana += float((prm.grad * v).sum())
+    nums = []
     with torch.no_grad():
-        for prm, v in zip(params, vs):
-            prm.add_(eps * v)
-        fp = float(fn())
-        for prm, v in zip(params, vs):
-            prm.sub_(2 * eps * v)
-        fm = float(fn())
-        for prm, v in zip(params, vs):
-            prm.add_(eps * v)
-    num = (fp - fm) / (2 * eps)
-    assert abs(ana - num) <= rel * max(abs(ana), abs(num)) + 1e-3, f"analytic {ana} vs numeric {num}"
+        for e in eps:
+            for prm, v in zip(params, vs):
+                prm.add_(e * v)
+            fp = float(fn())
+            for prm, v in zip(params, vs):
+                prm.sub_(2 * e * v)
+            fm = float(fn())
+            for prm, v in zip(params, vs):
+                prm.add_(e * v)
+            nums.append((fp - fm) / (2 * e))
+    tol = lambda num: rel * max(abs(ana), abs(num)) + 1e-3
+    close = any(abs(ana - num) <= tol(num) for num in nums)
+    inside = min(nums) - tol(min(nums)) <= ana <= max(nums) + tol(max(nums))
+    assert close or inside, f"analytic {ana} vs numeric {nums} at steps {eps}"
 
 
 def test_fusion_and_cross_attention_gradients_are_consistent_under_dropout(OP):
