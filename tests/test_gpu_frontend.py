@@ -198,3 +198,65 @@ def test_default_audio_encoder_runs_gates_and_conditioning_on_the_device():
     with torch.no_grad():
         seq_g, _ = ae([torch.from_numpy(x) for x in clips], gate_features=(q, c))
     assert not torch.allclose(seq_g, seq)
+
+
+@pytest.mark.parametrize("T", [2048, 2049, 8191, 8207, 12345, 16384 + 15, 160000])
+def test_front_end_odd_lengths_against_oracle(T):
+    """lengths around the kernels' internal boundaries (one analysis window, the 8192-sample filter tile with and without
+    the 2 x 15 / 2 x 9 padding samples, a 10 s clip): gates + conditioning of three clips per length (hum + rumble so that
+    both filters run, a tone so that the Wiener filter runs, an accepted clip) against the oracle."""
+    from oracle import dsp_oracle as D
+    from ser_amd import _ops as O
+    rs = np.random.RandomState(T)
+    t = np.arange(T) / 16000.0
+    speechy = sum(0.2 / (h + 1) * np.sin(2 * np.pi * 140 * (h + 1) * t + rs.uniform(0, 6)) for h in range(6)) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t))
+    clips = [(0.3 * speechy + 0.25 * np.sin(2 * np.pi * 50 * t) + 0.2 * np.sin(2 * np.pi * 60 * t + 1) + 0.1 * np.sin(2 * np.pi * 30 * t)),
+             0.4 * np.sin(2 * np.pi * 440 * t) + 0.01 * rs.randn(T),
+             accept_clip(T, rs, 150.0)]
+    clips = [c.astype(np.float32) for c in clips]
+    wave = _dev(np.stack(clips))
+    lid = _dev(np.tile(np.array([[1.0, 0.0]], dtype=np.float32), (3, 1)))
+    raw, met, dec = O.quality_gates(wave, lid)
+    out, c_raw, c_meta = O.audio_conditioning(wave)                  # conditioning of the clips themselves (no gating)
+    ran = np.zeros(3)
+    for b in range(3):
+        q = D.quality_metrics(clips[b], None)
+        c = D.condition_audio(clips[b])
+        np.testing.assert_allclose(raw[b].cpu().numpy(), q["features"], atol=3e-5, err_msg=f"quality {b}")
+        assert int(dec[b]) == DEC[q["decision"]]
+        np.testing.assert_allclose(out[b].cpu().numpy(), c["audio"], rtol=0, atol=2e-6 * max(1.0, np.abs(c["audio"]).max()), err_msg=f"audio {b}")
+        np.testing.assert_allclose(c_raw[b].cpu().numpy(), c["features"], atol=3e-5, err_msg=f"conditioning {b}")
+        ran += c["features"][:3]
+    assert ran[0] >= 1 and ran[1] >= 1 and (ran[2] >= 1 or T < 4000)
+
+
+def test_default_audio_encoder_on_ragged_clips():
+    """clips of different lengths: one front-end + encoder pass per distinct length, features scattered back in batch
+    order, the padded frames of the shorter clip stay zero (ref audio_encoder.py:129-166)."""
+    import warnings
+    from transformers import Wav2Vec2Config
+    from oracle import dsp_oracle as D
+    from oracle import ser_oracle as R
+    from ser_amd.models import AudioEncoder
+    torch.manual_seed(5)
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                        conv_dim=[64] * 7, num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ae = AudioEncoder(hf_config=wc, adapter_dim=32, vad_method="librosa").cuda().eval()
+    sd = {k: v.detach().cpu().float() for k, v in ae.state_dict().items()}
+    cfg = R.wav2vec2_config(hidden=128, layers=2, heads=2, ffn=256, conv_dim=(64,) * 7, pos_kernel=16, pos_groups=4)
+    rs = np.random.RandomState(9)
+    clips = [accept_clip(16000, rs, 150.0), accept_clip(12000, rs, 170.0), accept_clip(16000, rs, 130.0)]
+    with torch.no_grad():
+        seq, mask = ae([torch.from_numpy(c) for c in clips])
+    S = [R.wav2vec2_forward(R.sub(sd, "encoder."), torch.zeros(1, len(c)), cfg).shape[1] for c in clips]
+    assert seq.shape[1] == max(S) and bool(mask.all())
+    for i, c in enumerate(clips):
+        fe = D.front_end(c, None, None)
+        x = R.normalise_waveform(torch.from_numpy(fe["audio"]))[None]
+        s = R.adapter(R.wav2vec2_forward(R.sub(sd, "encoder."), x, cfg)[0], R.sub(sd, "adapter."))
+        s = R.gate_feature_fusion(sd, s[None], torch.from_numpy(fe["quality"]["features"])[None],
+                                  torch.from_numpy(fe["conditioning"]["features"])[None])[0]
+        np.testing.assert_allclose(seq[i, :S[i]].cpu().numpy(), s.numpy(), rtol=0, atol=3e-4, err_msg=str(i))
+        assert not seq[i, S[i]:].any()
