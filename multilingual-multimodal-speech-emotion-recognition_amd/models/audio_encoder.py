@@ -129,15 +129,22 @@ class AudioEncoder(nn.Module):
 
     def encode(self, wave: torch.Tensor) -> torch.Tensor:
         """[B,T] equal-length raw clips on the device -> [B,S,H] (encoder + adapter)."""
-        if not self.freeze_base:       # BASELINE config 3: every Wav2Vec2 parameter is trained (ref :15-17)
+        noisy = self.training and getattr(self, "encoder_train_noise", False)
+        if not self.freeze_base or noisy:
+            # freeze_base=False: BASELINE config 3, every Wav2Vec2 parameter is trained (ref :15-17).  encoder_train_noise:
+            # the encoder's own training-mode noise (HF dropout sites, LayerDrop, SpecAugment) - the reference calls
+            # .train() on the encoders even when they are frozen (src/train.py:124); masks / draws only inside an active
+            # dropout scope.  The frozen + noisy case runs the same forward without building a graph.
             from ._finetune import Noise, wav2vec2_forward
             noise = None
-            if self.training and getattr(self, "encoder_train_noise", False):
-                # the encoder's own training-mode noise (HF dropout sites, LayerDrop, SpecAugment: the reference calls
-                # .train() on the encoders, src/train.py:124); masks / draws only inside an active dropout scope
+            if noisy:
                 if getattr(self, "_noise", None) is None:
                     self._noise = Noise(self.encoder.config, 0, seed=getattr(self, "noise_seed", 0))
                 noise = self._noise
+            if self.freeze_base:
+                with torch.no_grad():
+                    seq = wav2vec2_forward(self.encoder, wave, noise)
+                return adapter_apply(self, seq)
             return adapter_apply(self, wav2vec2_forward(self.encoder, wave, noise))
         with torch.no_grad():
             seq = self.engine().forward(wave)

@@ -62,14 +62,21 @@ class TextEncoder(nn.Module):
         dev = self.adapter[0].weight.device
         ids = input_ids.to(dev)
         mask = attention_mask.to(dev)
-        if not self.freeze_base:       # BASELINE config 3: every XLM-R parameter is trained (ref :13-15)
+        noisy = self.training and getattr(self, "encoder_train_noise", False)
+        if not self.freeze_base or noisy:
+            # freeze_base=False: BASELINE config 3, every XLM-R parameter is trained (ref :13-15); encoder_train_noise: HF's
+            # training-mode dropout sites, which the reference leaves on for the frozen encoder too (src/train.py:124)
             from ._finetune import Noise, xlmr_forward
             noise = None
-            if self.training and getattr(self, "encoder_train_noise", False):
+            if noisy:
                 if getattr(self, "_noise", None) is None:
                     self._noise = Noise(self.encoder.config, 1, seed=getattr(self, "noise_seed", 0))
                 noise = self._noise
-            seq = xlmr_forward(self.encoder, ids, mask, noise)
+            if self.freeze_base:
+                with torch.no_grad():
+                    seq = xlmr_forward(self.encoder, ids, mask, noise)
+            else:
+                seq = xlmr_forward(self.encoder, ids, mask, noise)
             return adapter_apply(self, seq), mask.to(seq.dtype)
         with torch.no_grad():
             seq = self.engine().forward(ids, mask)

@@ -121,8 +121,10 @@ class SERSystem(nn.Module):
         """Frozen encoders (one paired call) + the two trainable adapters (independent: the text one on a second
         stream)."""
         from .models.adapter import adapter_apply
-        if not (self.audio_encoder.freeze_base and self.text_encoder.freeze_base):
-            # BASELINE config 3 (reference freeze_base=False): the fine-tuning form of the encoders, with gradients
+        noisy = self.training and (getattr(self.audio_encoder, "encoder_train_noise", False) or getattr(self.text_encoder, "encoder_train_noise", False))
+        if noisy or not (self.audio_encoder.freeze_base and self.text_encoder.freeze_base):
+            # BASELINE config 3 (reference freeze_base=False): the fine-tuning form of the encoders, with gradients; also the
+            # frozen encoders when their training-mode noise is requested (forward only, same operators)
             a_seq = self.audio_encoder.encode(wave.to(torch.float32))
             t_seq, t_mask = self.text_encoder.forward_ids(ids.to(wave.device), attn_mask.to(wave.device))
             a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)

@@ -73,6 +73,9 @@ def build_parser():
     p.add_argument('--no_bucketing', action='store_true', help='plain shuffled batches instead of length-bucketed ones')
     p.add_argument('--unfreeze_encoders', action='store_true',
                    help='BASELINE config 3: full fine-tune, every Wav2Vec2 / XLM-R parameter trained (reference freeze_base=False)')
+    p.add_argument('--encoder_train_noise', action='store_true',
+                   help="frozen encoders: run them with HF's training-mode noise (dropout sites, LayerDrop, SpecAugment), as the "
+                        "reference does by calling .train() on them (train.py:124); slower: fp32 three-product operators, no graph")
     p.add_argument('--no_encoder_noise', action='store_true',
                    help='with --unfreeze_encoders: leave out the encoders\' own training-mode noise (HF dropout sites, LayerDrop, '
                         'SpecAugment), which is on by default as in the reference (.train() on both encoders, src/train.py:124)')
@@ -142,13 +145,14 @@ class HipEngine:
         self.te = TextEncoder(args.text_model, precision=args.precision, freeze_base=frozen)
         self.sys = SERSystem(ae, self.te, num_labels=args.num_labels).to(device)
         self.sys.dropout_seed += rank              # every data-parallel rank draws its own dropout masks
-        if args.unfreeze_encoders and not args.no_encoder_noise:
+        noisy = (args.unfreeze_encoders and not args.no_encoder_noise) or args.encoder_train_noise
+        if noisy:
             for m in (ae, self.te):
                 m.encoder_train_noise, m.noise_seed = True, args.seed * 64 + rank
         self.opt = self.sys.make_optimizer(lr=args.lr)
         self.sched = WarmupCosine(self.opt, steps_per_epoch * args.epochs, args.warmup_ratio)
         self.reducer = GradReducer(self.sys) if world > 1 else None
-        noisy = args.unfreeze_encoders and not args.no_encoder_noise     # LayerDrop / SpecAugment are per-step host decisions: no graph
+        # LayerDrop / SpecAugment are per-step host decisions: no graph
         self.stepper = TrainStepper(self.sys, self.opt, self.sched, self.reducer, use_graph=args.graph and not noisy,
                                     use_proto=args.proto_weight > 0)
         self.aug = AugmentRng(args.seed, rank) if args.augment else None

@@ -222,3 +222,58 @@ def test_encoder_training_noise_matches_the_oracle_with_the_same_draws():
         gq = ae.encoder.encoder.layers[l].attention.q_proj.weight.grad
         assert gq is None or float(gq.abs().max()) == 0.0
     assert float(ae.encoder.masked_spec_embed.grad.abs().max()) > 0.0, "SpecAugment frames feed gradients to masked_spec_embed"
+
+
+def test_frozen_encoders_with_training_noise_match_the_oracle():
+    """freeze_base=True + encoder_train_noise: what the reference's train.py does to its frozen encoders (.train() on
+    both, src/train.py:124) - HF dropout sites, LayerDrop and SpecAugment on, no encoder gradients.  Outputs against the
+    oracle with the same draws; the encoder parameters stay without gradients and the adapters train."""
+    import ser_amd  # noqa: F401
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    from ser_amd import _ops as OP
+    from ser_amd.models import AudioEncoder, TextEncoder
+    import __graft_entry__ as ge
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
+                        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, layerdrop=0.3, mask_time_prob=0.3,
+                        mask_time_length=2, mask_time_min_masks=2)
+    xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                          max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    ae = AudioEncoder(hf_config=wc, adapter_dim=32, use_quality_gates=False, use_audio_conditioning=False).to(dev).train()
+    te = TextEncoder(hf_config=xc, adapter_dim=32).to(dev).train()
+    assert ae.freeze_base and te.freeze_base
+    ae.encoder_train_noise = te.encoder_train_noise = True
+    ae.noise_seed = 5
+    a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
+    g = torch.Generator().manual_seed(3)
+    B, T, S = 3, 4000, 9
+    wave = 0.1 * torch.randn(B, T, generator=g)
+    ids = torch.randint(4, 1000, (B, S), generator=g)
+    ids[:, 0], ids[:, -1] = 0, 2
+    mask = torch.ones(B, S)
+    state = torch.full((1,), 777, dtype=torch.int64, device=dev)
+    with OP.dropout_scope(state):
+        a_seq = ae.encode(wave.to(dev))
+        t_seq, _ = te.forward_ids(ids.to(dev), mask.to(dev))
+    (a_seq.sum() + t_seq.sum()).backward()
+    na, nt = ae._noise, te._noise
+    assert na.spec_mask is not None and na.spec_mask.any()
+    assert all(p.grad is None for p in ae.encoder.parameters()) and all(p.grad is None for p in te.encoder.parameters())
+    assert ae.adapter[0].weight.grad is not None and te.adapter[0].weight.grad is not None
+    sda = {n: v.detach().cpu().clone() for n, v in ae.state_dict().items()}
+    sdt = {n: v.detach().cpu().clone() for n, v in te.state_dict().items()}
+    noa = O.EncoderNoise(777, 0, na.p_hidden, na.p_attn, na.p_act, na.p_featproj, na.skip, na.spec_mask)
+    not_ = O.EncoderNoise(777, 1, nt.p_hidden, nt.p_attn, 0.0, 0.0)
+    x = torch.stack([O.normalise_waveform(w) for w in wave])
+    ra = O.adapter(O.wav2vec2_forward(O.sub(sda, "encoder."), x, a_cfg, noa), O.sub(sda, "adapter."))
+    rt = O.adapter(O.xlmr_forward(O.sub(sdt, "encoder."), ids, mask, t_cfg, not_), O.sub(sdt, "adapter."))
+    clean = O.adapter(O.wav2vec2_forward(O.sub(sda, "encoder."), x, a_cfg), O.sub(sda, "adapter."))
+    assert (clean - ra).abs().max().item() > 0.1, "the noise must change the output"
+    assert (a_seq.detach().cpu() - ra).abs().max().item() < 5e-4
+    assert (t_seq.detach().cpu() - rt).abs().max().item() < 5e-4
+    # eval mode: back on the bf16 engine, no noise
+    ae.eval()
+    with torch.no_grad():
+        e = ae.encode(wave.to(dev))
+    assert (e.cpu() - clean).abs().max().item() < 5e-4
