@@ -15,5 +15,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/${TAG}_pmc_w -o w -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-pipeline --no-cpu-baseline > /dev/null 2> gpurun_out/${TAG}_pmc_w.err; echo "pmc w rc=$?"
 python scripts/pmc_traffic.py gpurun_out/${TAG}_pmc_f/f_counter_collection.csv gpurun_out/${TAG}_pmc_w/w_counter_collection.csv gpurun_out/${TAG}_pmc_traffic.json > /dev/null 2>&1; echo "traffic rc=$?"
 cat gpurun_out/${TAG}_pmc_traffic.json | head -20
+timeout -k 10 400 python bench.py --unfreeze --batch 8 --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/${TAG}_bench_config3_full_finetune.json 2> gpurun_out/${TAG}_bench_config3.err; echo "config3 rc=$?"
+cut -c1-400 gpurun_out/${TAG}_bench_config3_full_finetune.json
+timeout -k 10 200 python scripts/frontend_timing.py > gpurun_out/${TAG}_frontend_timing.json 2> gpurun_out/${TAG}_frontend_timing.err; echo "frontend rc=$?"
+cat gpurun_out/${TAG}_frontend_timing.json
 rm -rf gpurun_out/${TAG}_pmc_f gpurun_out/${TAG}_pmc_w gpurun_out/${TAG}_prof/k_kernel_trace.csv
 head -25 gpurun_out/${TAG}_summary.md
