@@ -7,6 +7,8 @@ per `load_state_dict` (frozen encoders); the forward itself is one C call.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -212,7 +214,9 @@ _TUNED = set()
 TILE_HEIGHTS = (64, 96, 128, 160, 192)
 # interleaved three-product mode: also the single-LDS-buffer tiles (3000 + rows: three workgroups per CU) and the
 # 512-thread tiles (csrc/ser_common.h SER_GEMM_CFG_*); which wins depends on the shape (scripts/gemm_il_probe.py --cfgs)
-TILE_CONFIGS_X3 = TILE_HEIGHTS + (3064, 3096, 3128, 1192, 1256, 5128, 6256)
+# experiments: SER_GEMM_SKIP_FAMILIES="7,3" leaves the 7xxx (64-column) and 3xxx (single-buffer) tiles out of the timing pass
+_SKIP_CFG_FAMILIES = {int(x) for x in os.environ.get("SER_GEMM_SKIP_FAMILIES", "").split(",") if x.strip()}
+TILE_CONFIGS_X3 = TILE_HEIGHTS + (3064, 3096, 3128, 1192, 1256, 5128, 6256, 7064, 7096, 7128, 7192)
 
 
 def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
@@ -235,6 +239,10 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
         try:
             for bm in (TILE_CONFIGS_X3 if three_products else TILE_HEIGHTS):
                 if bm in (1192, 1256, 5128) and N < 256:
+                    continue
+                if bm // 1000 in _SKIP_CFG_FAMILIES:
+                    continue
+                if 7000 <= bm < 8000 and (rows // 64) * (N // 64) > 2048:      # 64-column tiles: only where the 128-column tilings are short of workgroups
                     continue
                 L.lib.ser_debug_set_gemm_bm(bm)
 

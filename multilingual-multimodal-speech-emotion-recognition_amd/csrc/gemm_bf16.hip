@@ -718,9 +718,25 @@ static int launch_single(int cfg, const SerGemmArgs* small, const SerGemmArgs& b
   return SER_E_ARG;
 }
 
+// 64-column tiles (interleaved three-product mode): twice the workgroups of the 128-column form for the N = 768 shapes,
+// whose 128-column tilings leave a quarter of the CUs with one workgroup or none
+static int launch_narrow(int cfg, const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+  SER_REQUIRE(gemm_mode(big) == M_X3I, "gemm_bf16: the 64-column tiles of the plan table are built for the interleaved three-product mode");
+  switch (cfg - SER_GEMM_CFG_NARROW) {
+    case 64: return launch_kernel<64, 64, M_X3I, 3, 2, 2>(small, big, st);
+    case 96: return launch_kernel<96, 64, M_X3I, 3, 2, 2>(small, big, st);
+    case 128: return launch_kernel<128, 64, M_X3I, 2, 2, 2>(small, big, st);
+    case 192: return launch_kernel<192, 64, M_X3I, 2, 2, 2>(small, big, st);
+    default: break;
+  }
+  ser_set_error("gemm_bf16: unknown tile configuration %d", cfg);
+  return SER_E_ARG;
+}
+
 static int launch_bn128(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
   const long long rows_a = small ? (long long)small->M * small->nb1 * small->nb2 : 0;
   const int cfg = big.cfg ? big.cfg : pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2, gemm_mode(big));
+  if (cfg >= SER_GEMM_CFG_NARROW && cfg < SER_GEMM_CFG_NARROW + 1000) return launch_narrow(cfg, small, big, st);
   if (cfg >= SER_GEMM_CFG_SINGLE && cfg < SER_GEMM_CFG_SINGLE + 1000) return launch_single(cfg, small, big, st);
   if (cfg >= SER_GEMM_CFG_WIDE) return launch_wide(cfg, small, big, st);
   switch (cfg) {

@@ -71,7 +71,8 @@ def test_gemm_interleaved_tile_heights_agree(L, bm):
 
 
 WIDE = {"128x256": 1128, "192x256": 1192, "256x256": 1256, "256x128": 2256, "single-buffer 64": 3064, "single-buffer 96": 3096,
-        "single-buffer 128": 3128, "128x256 3 buffers": 5128, "256x128 3 buffers": 6256}
+        "single-buffer 128": 3128, "128x256 3 buffers": 5128, "256x128 3 buffers": 6256,
+        "64x64": 7064, "96x64": 7096, "128x64": 7128, "192x64": 7192}
 
 
 def _gemm_cfg(L, a_il, w_il, M, N, K, cfg, ksplit=1):
