@@ -150,6 +150,30 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+def gemm_plans(args, wc):
+    """Tile configuration the engines' timing pass recorded for the four layer GEMMs of this run (SER_GEMM_CFG_* ids: rows
+    of a BM x 128 tile, 3xxx single-buffer, 7xxx BM x 64, 1xxx / 2xxx / 5xxx / 6xxx 512-thread tiles)."""
+    import ctypes as C
+    from ser_amd import _lib as L
+    try:
+        fn = L.lib.ser_gemm_plan_get
+        fn.restype = C.c_int
+        fn.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        T = int(16000 * args.seconds)
+        for k, st in zip(wc.conv_kernel, wc.conv_stride):
+            T = (T - k) // st + 1
+        rows = args.batch * T + args.batch * args.tokens
+        H, F = wc.hidden_size, wc.intermediate_size
+        out = {}
+        for name, N, K in (("qkv", 3 * H, H), ("oproj", H, H), ("ffn1", F, H), ("ffn2", H, F)):
+            cfg, ks = C.c_int(0), C.c_int(1)
+            fn(rows, N, K, 1 if args.precision == "bf16x3" else 0, C.byref(cfg), C.byref(ks))
+            out[name] = cfg.value
+        return out
+    except Exception as e:      # noqa: BLE001 - a reporting extra must never fail the bench line
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +364,8 @@ def main():
             "parity_on": "initial weights, before the first optimizer step", "oracle_logit_spread_across_clips": spread,
             "whole_step_algorithmic_tflops": None if step_tflops is None else round(step_tflops, 2),
             "loss": round(loss, 5),
+            "gemm_plans": gemm_plans(args, wc),
+            "gemm_plan_refinements_in_situ": [list(r) for r in getattr(stepper, "plan_refinements", [])],
         }
         print(json.dumps(out))
     if world > 1:

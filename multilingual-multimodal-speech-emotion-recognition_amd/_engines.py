@@ -211,6 +211,7 @@ class XlmrEngine:
 # the winners in the library (ser_gemm_tile_hint).  The arithmetic of a tile does not depend on its height, so this
 # changes speed only.  Skipped during graph capture (the eager warm-up pass has already run it) and in bf16x3 mode.
 _TUNED = set()
+_TUNE_RANKED = {}      # (rows, N, K, three_products) -> [(ms, cfg), ...] of the stand-alone timing pass, fastest first
 TILE_HEIGHTS = (64, 96, 128, 160, 192)
 # interleaved three-product mode: also the single-LDS-buffer tiles (3000 + rows: three workgroups per CU) and the
 # 512-thread tiles (csrc/ser_common.h SER_GEMM_CFG_*); which wins depends on the shape (scripts/gemm_il_probe.py --cfgs)
@@ -235,7 +236,7 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
         w = (torch.randn(N, K * pm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
         c = torch.empty(rows, N * pm, dtype=torch.bfloat16, device=device)
         lo = (lambda t: t.data_ptr() + 2 * L.IL_GROUP) if three_products else (lambda t: None)
-        best, best_ms = 0, float("inf")
+        best, best_ms, ranked = 0, float("inf"), []
         try:
             for bm in (TILE_CONFIGS_X3 if three_products else TILE_HEIGHTS):
                 if bm in (1192, 1256, 5128) and N < 256:
@@ -257,11 +258,30 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
                 e1.record()
                 e1.synchronize()
                 ms = e0.elapsed_time(e1)
+                ranked.append((ms, bm))
                 if ms < best_ms:
                     best, best_ms = bm, ms
         finally:
             L.lib.ser_debug_set_gemm_bm(0)
         L.lib.ser_gemm_tile_hint_mode(rows, N, K, 1 if three_products else 0, best)
+        _TUNE_RANKED[(int(rows), int(N), int(K), bool(three_products))] = sorted(ranked)
+
+
+def close_runner_ups(margin=1.06, limit=2):
+    """Shapes with other configurations within `margin` of the fastest in the stand-alone timing pass:
+    [((rows, N, K, three_products), best_cfg, [up to `limit` alternatives, fastest first])].  Stand-alone times this close
+    do not decide which one is faster beside the head graph (PipelinedStepper.refine_gemm_plans measures that)."""
+    out = []
+    for key, ranked in _TUNE_RANKED.items():
+        alts = [cfg for ms, cfg in ranked[1:1 + limit] if ms <= margin * ranked[0][0]]
+        if alts:
+            out.append((key, ranked[0][1], alts))
+    return out
+
+
+def set_plan(key, cfg):
+    rows, N, K, three = key
+    L.lib.ser_gemm_tile_hint_mode(rows, N, K, 1 if three else 0, int(cfg))
 
 
 def _w2v_gemm_shapes(cfg, B, T, extra_rows=0):

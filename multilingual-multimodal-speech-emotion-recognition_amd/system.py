@@ -495,6 +495,7 @@ class PipelinedStepper:
         # the 100 MB of gradients) is issued between them, so it travels over xGMI while B runs.  Same arithmetic as the
         # single graph (the two consumers of `fused` add their gradients in the detached leaf).
         self.split = (reducer is not None and reducer.early) if split_backward is None else bool(split_backward)
+        self.refine_plans = True          # in-situ choice between near-tied GEMM tile configurations (refine_gemm_plans)
         self.loss = None
         self.pending = False
 
@@ -526,11 +527,7 @@ class PipelinedStepper:
                     self.opt._mv(id(p), p.data)
         torch.cuda.current_stream().wait_stream(side)
         self.opt.zero_grad(set_to_none=True)
-        self.g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_enc):
-            a, t = s.encode_frozen(self.in_next[0], self.in_next[1], self.in_next[2])
-            self.enc_next[0].copy_(a)
-            self.enc_next[1].copy_(t)
+        self._capture_encoders()
         self.g_head = torch.cuda.CUDAGraph()
         if self.split:
             with torch.cuda.graph(self.g_head):
@@ -545,6 +542,62 @@ class PipelinedStepper:
         with torch.cuda.graph(self.g_opt):
             self.opt.launch()
         self._pick_encoder_stream()
+        if self.refine_plans:
+            self.refine_gemm_plans()
+
+    def _capture_encoders(self):
+        s = self.sys
+        self.g_enc = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_enc):
+            a, t = s.encode_frozen(self.in_next[0], self.in_next[1], self.in_next[2])
+            self.enc_next[0].copy_(a)
+            self.enc_next[1].copy_(t)
+
+    def _overlapped_ms(self, reps=6):
+        """Time of one replay of the encoder graph beside the head graph(s) (idempotent: no optimizer step involved)."""
+        cur, es = torch.cuda.current_stream(), self.enc_stream
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(reps):
+            es.wait_stream(cur)
+            with torch.cuda.stream(es):
+                self.g_enc.replay()
+            self.g_head.replay()
+            if self.g_head_b is not None:
+                self.g_head_b.replay()
+            cur.wait_stream(es)
+        e1.record(cur)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def refine_gemm_plans(self, gain=0.988):
+        """The engines pick a tile configuration per GEMM shape from stand-alone timings; where the runner-up is within a
+        few percent, which of the two is faster BESIDE the head graph is a different question (a 32 KB single-buffer tile
+        and an 86 KB three-stage tile tie alone and differ by 3 % of the step here).  For each such shape: switch the plan
+        to each close alternative, re-capture the encoder graph, time the overlapped replay, keep the fastest.  Results are
+        bit-identical either way (same products, same order per accumulator)."""
+        from . import _engines as E
+        self.plan_refinements = []
+        cands = E.close_runner_ups()
+        if not cands:
+            return
+        measure = lambda: min(self._overlapped_ms(8) for _ in range(3))
+        self._overlapped_ms(2)
+        base = measure()
+        for key, best, alts in cands:
+            keep = best
+            for alt in alts:
+                E.set_plan(key, alt)
+                self._capture_encoders()
+                self._overlapped_ms(2)
+                t = measure()
+                if t < base * gain:
+                    self.plan_refinements.append((key[:3], keep, alt, round(base, 3), round(t, 3)))
+                    base, keep = t, alt
+            E.set_plan(key, keep)
+            self._capture_encoders()
+        self.opt.zero_grad(set_to_none=True)
 
     def _head_a(self):
         s = self.sys
