@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoders and head back to back instead of encoder(t+1) beside head(t)")
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
+                    help="frozen-encoder passes in flight beside the head step: 1 = batch t+1, 2 = batches t+1 and t+2 (two encoder graphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -254,8 +256,9 @@ def main():
     pipeline = use_graph and not args.no_pipeline and not args.unfreeze     # unfrozen encoders depend on the last update: no overlap across steps
     if pipeline:
         from ser_amd.system import PipelinedStepper
-        stepper = PipelinedStepper(sysm, opt, None, reducer)
-        stepper.feed(*batches[0])       # encoders of the first batch; every step() then does one encoder pass + one update
+        stepper = PipelinedStepper(sysm, opt, None, reducer, depth=args.depth)
+        for j in range(args.depth):     # encoders of the first batch(es); every step() then does one encoder pass + one update
+            stepper.feed(*batches[j % 4])
     it = 0
     for _ in range(max(1, args.warmup)):
         it += 1
@@ -350,8 +353,11 @@ def main():
                                      "bf16x3: operands split into bf16 hi+lo planes, 3 bf16 MFMA products per multiply, fp32 accumulate"
                                      if args.precision == "bf16x3" else "bf16: 1 bf16 MFMA product per multiply, fp32 accumulate (fast mode, no 1e-3 parity claim)"),
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
-                       "schedule": "frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "
-                                   "(two streams; one encoder pass and one update per step)" if pipeline else "sequential",
+                       "schedule": (("frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "
+                                     "(two streams; one encoder pass and one update per step)") if args.depth == 1 else
+                                    ("frozen-encoder forwards of batches t+1 and t+2 in flight (two encoder graphs, two streams, own "
+                                     "workspaces) beside head fwd/bwd/AdamW of batch t; one encoder pass and one update per step"))
+                                   if pipeline else "sequential",
                        "stress_sizes": bool(args.stress),
                        "allreduce_overlap": (None if world == 1 else
                                              ("classifier bucket (76 of 100 MB) all-reduced over RCCL beside the backward of fusion / pooling / "

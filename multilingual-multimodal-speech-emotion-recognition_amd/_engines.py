@@ -298,7 +298,7 @@ def _w2v_gemm_shapes(cfg, B, T, extra_rows=0):
     return shapes
 
 
-def forward_pair(audio_engine, text_engine, wave, ids, attn_mask):
+def forward_pair(audio_engine, text_engine, wave, ids, attn_mask, slot=0):
     """Both frozen encoders in ONE call on the current stream (ser_encoders_forward): when the two models have the
     same depth their layers run in lock-step with one launch per step for both.  -> (a_enc [B,S_a,H], t_enc [B,S_t,H])."""
     a, t = audio_engine, text_engine
@@ -316,7 +316,9 @@ def forward_pair(audio_engine, text_engine, wave, ids, attn_mask):
     nt = L.lib.ser_xlmr_workspace_bytes(C.byref(t.cfg), Bt, St, t.prec)
     if na == 0 or nt == 0:
         L.check(-1, "ser_*_workspace_bytes")
-    wsa, wst = a.ws.get(na, wave.device), t.ws.get(nt, ids.device)
+    # slot > 0: a second workspace pair, for an encoder pass that runs beside another one (PipelinedStepper depth 2)
+    wsa = (a.ws if slot == 0 else a.__dict__.setdefault('_ws_slots', {}).setdefault(slot, _Workspace())).get(na, wave.device)
+    wst = (t.ws if slot == 0 else t.__dict__.setdefault('_ws_slots', {}).setdefault(slot, _Workspace())).get(nt, ids.device)
     if a.cfg.layers == t.cfg.layers and a.cfg.hidden == t.cfg.hidden:
         tune_gemm_shapes(_w2v_gemm_shapes(a.cfg, B, T, extra_rows=Bt * St), wave.device, three_products=a.prec == L.PREC_BF16X3)
     out_a = torch.empty(B, Sa, a.hidden, dtype=torch.float32, device=wave.device)

@@ -145,11 +145,11 @@ class SERSystem(nn.Module):
         return a_seq, a_mask, t_seq, attn_mask.to(device=a_seq.device, dtype=torch.float32)
 
     @torch.no_grad()
-    def encode_frozen(self, wave, ids, attn_mask):
+    def encode_frozen(self, wave, ids, attn_mask, slot=0):
         """Only the frozen part (no adapters): Wav2Vec2 and XLM-R forward -> (a_enc, t_enc).  One C call walks both
         models; with equal depth their layers share launches (ser_encoders_forward)."""
         from ._engines import forward_pair
-        return forward_pair(self.audio_encoder.engine(), self.text_encoder.engine(), wave, ids, attn_mask)
+        return forward_pair(self.audio_encoder.engine(), self.text_encoder.engine(), wave, ids, attn_mask, slot)
 
     def _set_precision(self):
         from . import _lib as L
@@ -486,10 +486,17 @@ class PipelinedStepper:
     previously and starts the encoders on `next_batch`.
     """
 
-    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_proto=True, split_backward=None):
+    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_proto=True, split_backward=None, depth=1):
         self.sys, self.opt, self.sched, self.reducer, self.use_proto = system, optimizer, scheduler, reducer, use_proto
-        self.enc_stream = torch.cuda.Stream()
-        self.g_enc = self.g_head = self.g_head_b = self.g_opt = None
+        # depth = encoder passes in flight: 1 = the encoders of batch t+1 beside the head of batch t; 2 = those of t+1 and
+        # t+2 beside it (two encoder graphs on two streams with their own workspaces: one chain's small kernels - attention,
+        # LayerNorm, tile tails - run under the other's GEMMs).  Either way every step runs exactly one encoder pass and
+        # one update; `feed` must be called `depth` times before the first `step`.
+        assert depth in (1, 2)
+        self.depth = depth
+        self.enc_streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.g_encs = [None] * depth
+        self.g_head = self.g_head_b = self.g_opt = None
         # Data parallel: the head graph is captured in two pieces — A: forward + loss + classifier backward, B: the
         # backward of fusion / pooling / cross-attention / adapters — and the all-reduce of the classifier bucket (76 MB of
         # the 100 MB of gradients) is issued between them, so it travels over xGMI while B runs.  Same arithmetic as the
@@ -497,10 +504,28 @@ class PipelinedStepper:
         self.split = (reducer is not None and reducer.early) if split_backward is None else bool(split_backward)
         self.refine_plans = True          # in-situ choice between near-tied GEMM tile configurations (refine_gemm_plans)
         self.loss = None
-        self.pending = False
+        self.queue, self.free = [], list(range(depth))       # slots whose encoder pass is in flight (oldest first) / unused
+
+    # single-slot names kept for the measurement scripts
+    @property
+    def g_enc(self):
+        return self.g_encs[0]
+
+    @property
+    def enc_stream(self):
+        return self.enc_streams[0]
+
+    @enc_stream.setter
+    def enc_stream(self, st):
+        self.enc_streams[0] = st
+
+    @property
+    def pending(self):
+        return len(self.queue) > 0
 
     def _alloc(self, wave, ids, mask, labels):
-        self.in_next = [wave.clone(), ids.clone(), mask.clone(), labels.clone()]      # inputs of the encoder graph
+        self.in_slots = [[wave.clone(), ids.clone(), mask.clone(), labels.clone()] for _ in range(self.depth)]   # encoder graph inputs
+        self.in_next = self.in_slots[0]
         self.cur_mask, self.cur_labels = mask.clone(), labels.clone()                # inputs of the head graph
         self.nxt_labels = labels.clone()
 
@@ -510,8 +535,11 @@ class PipelinedStepper:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):            # warm-up outside capture
-            a, t = s.encode_frozen(self.in_next[0], self.in_next[1], self.in_next[2])
-            self.enc_next = [a.clone(), t.clone()]
+            self.enc_slots = []
+            for k in range(self.depth):
+                a, t = s.encode_frozen(self.in_slots[k][0], self.in_slots[k][1], self.in_slots[k][2], slot=k)
+                self.enc_slots.append([a.clone(), t.clone()])
+            self.enc_next = self.enc_slots[0]
             self.enc_cur = [a.clone(), t.clone()]
             for _ in range(2):
                 self.opt.zero_grad(set_to_none=True)
@@ -547,26 +575,34 @@ class PipelinedStepper:
 
     def _capture_encoders(self):
         s = self.sys
-        self.g_enc = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_enc):
-            a, t = s.encode_frozen(self.in_next[0], self.in_next[1], self.in_next[2])
-            self.enc_next[0].copy_(a)
-            self.enc_next[1].copy_(t)
+        for k in range(self.depth):
+            self.g_encs[k] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_encs[k]):
+                a, t = s.encode_frozen(self.in_slots[k][0], self.in_slots[k][1], self.in_slots[k][2], slot=k)
+                self.enc_slots[k][0].copy_(a)
+                self.enc_slots[k][1].copy_(t)
 
-    def _overlapped_ms(self, reps=6):
-        """Time of one replay of the encoder graph beside the head graph(s) (idempotent: no optimizer step involved)."""
-        cur, es = torch.cuda.current_stream(), self.enc_stream
+    def _replay_all(self, streams=None):
+        """Every encoder graph on its stream beside the head graph(s), joined (idempotent: no optimizer step involved)."""
+        cur = torch.cuda.current_stream()
+        streams = streams or self.enc_streams
+        for k, es in enumerate(streams):
+            es.wait_stream(cur)
+            with torch.cuda.stream(es):
+                self.g_encs[k].replay()
+        self.g_head.replay()
+        if self.g_head_b is not None:
+            self.g_head_b.replay()
+        for es in streams:
+            cur.wait_stream(es)
+
+    def _overlapped_ms(self, reps=6, streams=None):
+        cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(cur)
         for _ in range(reps):
-            es.wait_stream(cur)
-            with torch.cuda.stream(es):
-                self.g_enc.replay()
-            self.g_head.replay()
-            if self.g_head_b is not None:
-                self.g_head_b.replay()
-            cur.wait_stream(es)
+            self._replay_all(streams)
         e1.record(cur)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
@@ -628,53 +664,44 @@ class PipelinedStepper:
 
     def _pick_encoder_stream(self, candidates=6, reps=3):
         """HIP multiplexes streams onto a few hardware queues; two streams that land on the same queue run their
-        graphs back to back.  Replay the two captured graphs beside each other on a few fresh streams and keep the
-        stream on which they actually overlap (replays are idempotent: no optimizer step is involved)."""
-        cur = torch.cuda.current_stream()
-        best, best_ms = self.enc_stream, float("inf")
-        for es in [self.enc_stream] + [torch.cuda.Stream() for _ in range(candidates - 1)]:
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-            for _ in range(reps):
-                es.wait_stream(cur)
-                with torch.cuda.stream(es):
-                    self.g_enc.replay()
-                self.g_head.replay()
-                if self.g_head_b is not None:
-                    self.g_head_b.replay()
-                cur.wait_stream(es)
-            e1.record(cur)
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
-            if ms < best_ms * 0.97:
-                best, best_ms = es, ms
-        self.enc_stream = best
-        self.overlap_ms = best_ms
+        graphs back to back.  Replay the captured graphs beside each other on a few fresh streams and keep, slot by
+        slot, the stream on which they actually overlap (replays are idempotent: no optimizer step is involved)."""
+        for k in range(self.depth):
+            best, best_ms = self.enc_streams[k], float("inf")
+            for es in [self.enc_streams[k]] + [torch.cuda.Stream() for _ in range(candidates - 1)]:
+                ms = self._overlapped_ms(reps, self.enc_streams[:k] + [es])
+                if ms < best_ms * 0.97:
+                    best, best_ms = es, ms
+            self.enc_streams[k] = best
+            self.overlap_ms = best_ms
         self.opt.zero_grad(set_to_none=True)
 
     def feed(self, wave, ids, mask, labels):
-        """Start the encoders on a batch (encoder stream); its head step happens in the next `step` call."""
-        if self.g_enc is None:
+        """Start the encoders on a batch (a free slot's stream); its head step happens `depth` `step` calls later."""
+        if self.g_encs[0] is None:
             self._capture(wave, ids, mask, labels)
-        es, cur = self.enc_stream, torch.cuda.current_stream()
-        es.wait_stream(cur)                       # previous users of in_next / enc_next on the main stream are done
+        assert self.free, "every encoder slot is in flight: call step() before feeding again"
+        k = self.free.pop(0)
+        es, cur = self.enc_streams[k], torch.cuda.current_stream()
+        es.wait_stream(cur)                       # previous users of this slot's buffers on the main stream are done
         with torch.cuda.stream(es):
-            for dst, src in zip(self.in_next, (wave, ids, mask, labels)):
+            for dst, src in zip(self.in_slots[k], (wave, ids, mask, labels)):
                 dst.copy_(src, non_blocking=True)
-            self.g_enc.replay()
-        self.pending = True
+            self.g_encs[k].replay()
+        self.queue.append(k)
 
     def step(self, wave, ids, mask, labels):
-        """Head step on the batch fed last time, encoders of this batch alongside it."""
-        assert self.pending, "call feed(batch) once before the first step"
+        """Head step on the oldest batch in flight, encoders of this batch alongside it."""
+        assert len(self.queue) == self.depth, f"call feed(batch) {self.depth} time(s) before the first step"
         dev = wave.device
         cur = torch.cuda.current_stream()
-        cur.wait_stream(self.enc_stream)          # encoder outputs of the batch to train on are ready
-        self.enc_cur[0].copy_(self.enc_next[0], non_blocking=True)
-        self.enc_cur[1].copy_(self.enc_next[1], non_blocking=True)
-        self.cur_mask.copy_(self.in_next[2], non_blocking=True)
-        self.cur_labels.copy_(self.in_next[3], non_blocking=True)
+        k = self.queue.pop(0)
+        cur.wait_stream(self.enc_streams[k])      # encoder outputs of the batch to train on are ready
+        self.enc_cur[0].copy_(self.enc_slots[k][0], non_blocking=True)
+        self.enc_cur[1].copy_(self.enc_slots[k][1], non_blocking=True)
+        self.cur_mask.copy_(self.in_slots[k][2], non_blocking=True)
+        self.cur_labels.copy_(self.in_slots[k][3], non_blocking=True)
+        self.free.append(k)
         self.feed(wave, ids, mask, labels)        # encoders of the NEXT batch: other stream, runs beside the head
         self.g_head.replay()
         if self.g_head_b is not None:

@@ -110,7 +110,10 @@ def test_graph_step_equals_eager_step():
         assert torch.equal(pa, pc), f"{n}: parameters diverged between eager and split-graph stepping"
 
 
-def test_pipelined_stepping_is_bit_identical_to_sequential():
+@pytest.mark.parametrize("depth", [1, 2])
+def test_pipelined_stepping_is_bit_identical_to_sequential(depth):
+    """depth = encoder passes in flight beside the head step (1: batch t+1; 2: batches t+1 and t+2, two encoder graphs
+    with their own workspaces): the same losses and parameters as stepping one batch at a time."""
     import __graft_entry__ as ge
     from ser_amd.system import PipelinedStepper, TrainStepper
     dev = torch.device("cuda:0")
@@ -120,13 +123,14 @@ def test_pipelined_stepping_is_bit_identical_to_sequential():
     sys_a.train(); sys_b.train()
     oa, ob = sys_a.make_optimizer(lr=1e-3), sys_b.make_optimizer(lr=1e-3)
     seq = TrainStepper(sys_a, oa, use_graph=False)
-    pipe = PipelinedStepper(sys_b, ob)
+    pipe = PipelinedStepper(sys_b, ob, depth=depth)
     batches = [[t.to(dev) for t in _batch(200 + i)] for i in range(5)]
     seq_losses = [seq.step(*b).item() for b in batches]
-    pipe.feed(*batches[0])
+    for j in range(depth):
+        pipe.feed(*batches[j])
     pipe_losses = []
     for i in range(5):
-        nxt = batches[i + 1] if i + 1 < 5 else batches[0]
+        nxt = batches[(i + depth) % 5]
         pipe_losses.append(pipe.step(*nxt).item())
     torch.cuda.synchronize()
     assert seq_losses == pipe_losses, (seq_losses, pipe_losses)
