@@ -485,7 +485,7 @@ L._sig("ser_frontend_workspace_bytes", L.sz, L.i32, L.i32)
 L._sig("ser_frontend_init", L.i32)
 L._sig("ser_quality_gates", L.i32, L.vp, L.i32, L.i32, L.i32, L.vp, L.i32, L.vp, L.vp, L.vp, L.vp, L.sz, L.vp)
 L._sig("ser_audio_conditioning", L.i32, L.vp, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp, L.sz, L.vp)
-_FE_WS = {}
+_FE_WS = {}      # device -> workspace, grow-only; the two calls below are meant for ONE stream at a time per device (like the engines' workspaces)
 
 
 def _frontend_ws(B, T, dev):
