@@ -421,6 +421,8 @@ class TrainStepper:
                     self.g_opt = g_opt                          # the optimizer launch does not depend on the input shape
                 self._graphs[key] = (self.static, self.g_fb, self.g_b, self.loss, self.logits)
             self.static, self.g_fb, self.g_b, self.loss, self.logits = self._graphs[key]
+            for p_, g_ in getattr(self, "_loose_grads", ()):      # a caller's zero_grad(set_to_none=True) must not detach them
+                p_.grad = g_
             for s, t in zip(self.static, (wave, ids, mask, labels)):
                 s.copy_(t, non_blocking=True)
             self.g_fb.replay()
@@ -456,16 +458,31 @@ class TrainStepper:
                     self.opt._mv(id(p), p.data)
         torch.cuda.current_stream().wait_stream(side)
         self.opt.zero_grad(set_to_none=True)
+        # Parameters outside the flat buckets (the prototypes) get their gradient as a tensor of the captured graph.  The
+        # optimizer graph is captured once and the reducer reads `p.grad`, so every later graph set (another input shape)
+        # must write the SAME tensor: it is handed back to autograd, zeroed inside the capture and accumulated into.
+        keep = getattr(self, "_loose_grads", None)
+        if keep:
+            for p_, g_ in keep:
+                p_.grad = g_
+
+        def zero_kept():
+            for _, g_ in keep or ():
+                g_.zero_()
         self.g_fb = torch.cuda.CUDAGraph()
         if self.split:
             with torch.cuda.graph(self.g_fb):
+                zero_kept()
                 self.loss, self.logits = self._fwd_bwd_a(*self.static)
             self.g_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_b, pool=self.g_fb.pool()):
                 self._bwd_b()
         else:
             with torch.cuda.graph(self.g_fb):
+                zero_kept()
                 self.loss, self.logits = self._fwd_bwd(*self.static)
+        if not keep:
+            self._loose_grads = [(p_, p_.grad) for grp, segs, loose in self.opt._plan for p_ in loose if p_.grad is not None]
         if self.g_opt is None or not self._graphs:
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt):
@@ -569,6 +586,10 @@ class PipelinedStepper:
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt):
             self.opt.launch()
+        # gradients of the parameters outside the flat buckets (the prototypes) live in tensors the captured head graph writes
+        # on every replay; `zero_grad(set_to_none=True)` below would drop the references, and a reducer that finds
+        # `p.grad is None` skips the parameter - its replicas then drift apart (tests/test_gpu_dp.py)
+        self._loose_grads = [(p, p.grad) for grp, segs, loose in self.opt._plan for p in loose if p.grad is not None]
         self._pick_encoder_stream()
         if self.refine_plans:
             self.refine_gemm_plans()
@@ -633,7 +654,7 @@ class PipelinedStepper:
                     base, keep = t, alt
             E.set_plan(key, keep)
             self._capture_encoders()
-        self.opt.zero_grad(set_to_none=True)
+        self._reset_grads_after_idle_replays()
 
     def _head_a(self):
         s = self.sys
@@ -674,7 +695,12 @@ class PipelinedStepper:
                     best, best_ms = es, ms
             self.enc_streams[k] = best
             self.overlap_ms = best_ms
+        self._reset_grads_after_idle_replays()
+
+    def _reset_grads_after_idle_replays(self):
         self.opt.zero_grad(set_to_none=True)
+        for p, g in self._loose_grads:           # keep pointing at the tensors the captured graphs write (see _capture)
+            p.grad = g
 
     def feed(self, wave, ids, mask, labels):
         """Start the encoders on a batch (a free slot's stream); its head step happens `depth` `step` calls later."""
@@ -696,6 +722,8 @@ class PipelinedStepper:
         dev = wave.device
         cur = torch.cuda.current_stream()
         k = self.queue.pop(0)
+        for p_, g_ in self._loose_grads:          # a caller's zero_grad(set_to_none=True) must not detach them (see _capture)
+            p_.grad = g_
         cur.wait_stream(self.enc_streams[k])      # encoder outputs of the batch to train on are ready
         self.enc_cur[0].copy_(self.enc_slots[k][0], non_blocking=True)
         self.enc_cur[1].copy_(self.enc_slots[k][1], non_blocking=True)

@@ -88,3 +88,64 @@ def test_two_ranks_one_gpu_gloo():
         p.join(300)
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert [r[1] for r in res] == ["ok", "ok"], res
+
+
+def _worker_pipelined(rank, world, port, q):
+    """The timed schedule under data parallelism: PipelinedStepper with two encoder passes in flight and the head graph
+    captured in two pieces with the classifier bucket's all-reduce between them (what `reducer.early` selects under
+    RCCL; forced here over gloo)."""
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SER_DP_EARLY="1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import __graft_entry__ as ge
+        from ser_amd.system import GradReducer, PipelinedStepper, TrainStepper
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        sys_a, _, _ = ge._small_system(dev)
+        sys_b, _, _ = ge._small_system(dev)
+        sys_b.load_state_dict(sys_a.state_dict())
+        sys_a.train(); sys_b.train()
+        batches = [[t.to(dev) for t in _batch(300 + 10 * i + rank)] for i in range(5)]
+        # reference: one batch at a time, eager, all buckets reduced after backward
+        oa = sys_a.make_optimizer(lr=1e-3)
+        ra = GradReducer(sys_a, overlap=False)
+        seq = TrainStepper(sys_a, oa, None, ra, use_graph=False)
+        seq_losses = [seq.step(*b).item() for b in batches]
+        # the timed schedule
+        ob = sys_b.make_optimizer(lr=1e-3)
+        rb = GradReducer(sys_b)
+        assert rb.early
+        pipe = PipelinedStepper(sys_b, ob, None, rb, depth=2)
+        assert pipe.split
+        pipe.feed(*batches[0]); pipe.feed(*batches[1])
+        pipe_losses = [pipe.step(*batches[(i + 2) % 5]).item() for i in range(5)]
+        torch.cuda.synchronize()
+        # same arithmetic up to the summation order of the reduction and of the two consumers of `fused`: the first loss
+        # (before any update) is identical, later ones drift by rounding amplified through AdamW (lr 1e-3); a bucket that
+        # was not averaged, or averaged twice, would move every parameter by O(lr) per step instead
+        assert seq_losses[0] == pipe_losses[0] and seq_losses == pytest.approx(pipe_losses, abs=1e-3), (seq_losses, pipe_losses)
+        fa = torch.cat([p.detach().reshape(-1) for p in sys_a.parameters() if p.requires_grad])
+        fb = torch.cat([p.detach().reshape(-1) for p in sys_b.parameters() if p.requires_grad])
+        assert (fa - fb).abs().mean().item() < 5e-5, f"pipelined DP schedule drifted from sequential DP stepping: mean |diff| {(fa - fb).abs().mean().item()}"
+        parts = [torch.empty_like(fb) for _ in range(world)]
+        dist.all_gather(parts, fb)
+        assert torch.equal(parts[0], parts[1]), "replicas diverged under the pipelined schedule"
+        q.put((rank, "ok"))
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc()))
+        raise
+
+
+def test_two_ranks_pipelined_split_backward_schedule():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(400)
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert [r[1] for r in res] == ["ok", "ok"], res

@@ -202,3 +202,31 @@ def test_train_step_with_dropout_matches_oracle_with_the_same_masks():
             denom = max(v.grad.abs().max().item(), 1e-3)
             rel = (named[n].grad.cpu() - v.grad).abs().max().item() / denom
             assert rel < 2e-2, f"{key}.{n}: gradient differs from the oracle under dropout (rel {rel:.3e})"
+
+
+def test_graph_stepping_over_several_input_shapes_equals_eager_stepping():
+    """Real manifests give a few distinct (clip length, token count, batch size) shapes; TrainStepper keeps one captured
+    graph set per shape but ONE optimizer graph.  The parameters outside the flat gradient buckets (the prototypes) must
+    therefore receive their gradient in the same tensor whatever graph set ran - otherwise the optimizer graph reads the
+    first shape's stale gradient.  Alternating three shapes, also with the caller clearing gradients between steps:
+    bit-identical to eager stepping."""
+    import __graft_entry__ as ge
+    from ser_amd.system import TrainStepper
+    dev = torch.device("cuda:0")
+    sys_a, _, _ = ge._small_system(dev)
+    sys_b, _, _ = ge._small_system(dev)
+    sys_b.load_state_dict(sys_a.state_dict())
+    sys_a.train(); sys_b.train()
+    oa, ob = sys_a.make_optimizer(lr=1e-3), sys_b.make_optimizer(lr=1e-3)
+    eager, graph = TrainStepper(sys_a, oa, use_graph=False), TrainStepper(sys_b, ob, use_graph=True)
+    shapes = [dict(B=4, T=4000, S=9), dict(B=4, T=3200, S=7), dict(B=2, T=4000, S=9)]
+    for it in range(7):
+        batch = [t.to(dev) for t in _batch(400 + it, **shapes[it % 3])]
+        la, lb = eager.step(*batch), graph.step(*batch)
+        torch.cuda.synchronize()
+        assert la.item() == lb.item(), f"step {it} (shape {shapes[it % 3]}): eager {la.item()} vs graph {lb.item()}"
+        if it == 3:
+            ob.zero_grad(set_to_none=True)          # what a hand-written loop would do between steps
+    assert len(graph._graphs) == 3
+    for (n, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
+        assert torch.equal(pa, pb), f"{n}: parameters diverged between eager and multi-shape graph stepping"
