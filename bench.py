@@ -324,7 +324,11 @@ def main():
                     launches_per_step=n.value // nprof,
                     avg_launch_us=round(ms.value * 1e3 / max(1, n.value), 2),
                     algorithmic_gflop_per_step=round(fl.value / nprof / 1e9, 1),
-                    mfma_products_per_mac=nprod)
+                    mfma_products_per_mac=nprod,
+                    note=("achieved / frac count algorithmic FLOPs (2 M N K); the parity mode executes mfma_products_per_mac bf16 MFMA "
+                          "products per multiply, so the matrix pipes run at mfma_pipe_utilisation = products x frac of the dense bf16 "
+                          "peak.  Context (profiles/r02_c_gemm_vs_vendor.txt): hipBLASLt's one-product bf16 kernels reach 25-26 % of "
+                          "peak on the same M = 3696 layer shapes and 38-58 % on the conv / 4096^3 shapes"))
     if world > 1:
         dist.barrier()
 
