@@ -232,6 +232,8 @@ def main():
             L.lib.ser_debug_set_gemm_stages_tall(*st[4:])
     if os.environ.get("SER_GEMM_LDS_PAD"):
         L.lib.ser_debug_set_gemm_lds_pad(int(os.environ["SER_GEMM_LDS_PAD"]))
+    if os.environ.get("SER_POSCONV_GEMM"):          # A/B: the positional conv through the sliding-window GEMM instead of posconv.hip
+        L.lib.ser_debug_set_posconv_gemm(int(os.environ["SER_POSCONV_GEMM"]))
     if os.environ.get("SER_GEMM_PERSIST"):
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
     sysm, wc, xc = build_system(args.precision, dev, stress=args.stress, unfreeze=args.unfreeze)

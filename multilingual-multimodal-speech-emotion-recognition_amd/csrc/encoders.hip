@@ -3,6 +3,9 @@
 // no synchronisation, so the call can be captured into a hipGraph).
 #include "ser_common.h"
 
+static int g_posconv_force_gemm = 0;      // tests: take the GEMM path where the resident-slab kernel would run
+extern "C" int ser_debug_set_posconv_gemm(int on) { g_posconv_force_gemm = on; return 0; }
+
 namespace {
 
 struct Planes {
@@ -249,7 +252,11 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
     g.bias = w->fp_b; g.c_f32 = z; g.ldc = H;
     SER_TRY(ser_launch_gemm_bf16(g, st));
   }
-  // positional conv embedding as a (clip, group)-batched sliding-window GEMM + GELU + residual
+  // positional conv embedding: the resident-slab kernel (posconv.hip) where it applies, else a (clip, group)-batched
+  // sliding-window GEMM + GELU + residual over a slab in global memory (long clips, one-product and planar modes)
+  if (pos_il && !g_posconv_force_gemm && ser_posconv_direct_ok(S, H, G, Kp)) {
+    SER_TRY(ser_launch_posconv_direct(z, w->pos_w.hi, w->pos_b, hsum, B, S, H, G, Kp, st));
+  } else {
   SER_TRY(ser_launch_posconv_slab(z, B, S, H, G, Kp, slab.hi, slab.lo, st));
   {
     const long long R = S + Kp - 1;
@@ -262,6 +269,7 @@ static int w2v_run(const SerW2vConfig* c, const SerW2vWeights* w, const float* w
     g.residual = z; g.ldr = H; g.sr1 = (long long)S * H; g.sr2 = Cg;
     g.c_f32 = hsum; g.ldc = H; g.sc1 = (long long)S * H; g.sc2 = Cg;
     SER_TRY(ser_launch_gemm_bf16(g, st));
+  }
   }
   SER_TRY(ser_launch_layernorm(hsum, nullptr, w->enc_ln_g, w->enc_ln_b, c->eps, (int)rows, H, ha, hpa.hi, hpa.lo, st));
   float* hin = ha; float* hout = hb;
@@ -391,4 +399,27 @@ extern "C" int ser_encoders_forward(const SerW2vConfig* wcfg, const SerW2vWeight
   const bool text_small = (long long)ct.B * ct.S <= (long long)ca.B * ca.S;
   for (int l = 0; l < wcfg->layers; ++l) SER_TRY(text_small ? run_layer_pair(ct, ca, l, st) : run_layer_pair(ca, ct, l, st));
   return SER_OK;
+}
+
+
+// tests: the positional conv on its own through either path.  z [B,S,H] fp32, w_il = interleaved weights [G*Cg][K*64],
+// slab_il: B*G*(S+K-1)*64*2 + K*64*2 bf16 of scratch (GEMM path only).
+extern "C" int ser_debug_posconv(const float* z, const uint16_t* w_il, const float* bias, float* out, int B, int S, int H, int G, int K,
+                                 int direct, uint16_t* slab_il, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int Cg = H / G, Cgp = 64;
+  if (direct) return ser_launch_posconv_direct(z, w_il, bias, out, B, S, H, G, K, st);
+  Planes slab{slab_il, slab_il + SER_IL_GROUP};
+  SER_TRY(ser_launch_posconv_slab(z, B, S, H, G, K, slab.hi, slab.lo, st));
+  const long long R = S + K - 1;
+  SerSplitW ww{w_il, w_il + SER_IL_GROUP};
+  SerGemmArgs g = gemm_args(slab, Cgp, ww, K * Cgp, S, Cg, K * Cgp);
+  g.nb1 = B; g.nb2 = G;
+  g.sa1 = (long long)G * R * Cgp; g.sa2 = R * Cgp;
+  g.sw1 = 0; g.sw2 = (long long)Cg * K * Cgp;
+  g.bias = bias; g.sbias1 = 0; g.sbias2 = Cg;
+  g.act = SER_ACT_GELU;
+  g.residual = z; g.ldr = H; g.sr1 = (long long)S * H; g.sr2 = Cg;
+  g.c_f32 = out; g.ldc = H; g.sc1 = (long long)S * H; g.sc2 = Cg;
+  return ser_launch_gemm_bf16(g, st);
 }

@@ -229,6 +229,9 @@ size_t ser_conv0_scratch_bytes(int B, int L0, int C0);
 int ser_launch_conv0(const float* wave, int B, int T, const float* w, const float* gn_g, const float* gn_b, int C0,
                      int KW, int ST, int L0, bf16_t* yhi, bf16_t* ylo, void* scratch, hipStream_t st);
 int ser_launch_posconv_slab(const float* z, int B, int S, int H, int G, int K, bf16_t* hi, bf16_t* lo, hipStream_t st);
+// the whole positional conv (+ bias, GELU, residual) with the (clip, group) slab resident in LDS (posconv.hip); interleaved weights
+int ser_posconv_direct_ok(int S, int H, int G, int K);
+int ser_launch_posconv_direct(const float* z, const bf16_t* w_il, const float* bias, float* out, int B, int S, int H, int G, int K, hipStream_t st);
 int ser_launch_xlmr_embed(const int64_t* ids, int B, int S, const float* wemb, const float* pemb, const float* temb,
                           const float* gamma, const float* beta, float eps, int D, int vocab, int max_pos, int pad_id,
                           int* pos_scratch, float* y, bf16_t* yhi, bf16_t* ylo, hipStream_t st);

@@ -27,6 +27,9 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if os.environ.get("SER_POSCONV_GEMM"):
+        from ser_amd import _lib as L
+        L.lib.ser_debug_set_posconv_gemm(int(os.environ["SER_POSCONV_GEMM"]))
     sysm, wc, xc = bench.build_system(a.precision, dev)
     sysm.eval()
     batches = [[t.to(dev) for t in bench.synth_batch(a.batch, a.seconds, a.tokens, xc.vocab_size, sysm.num_labels, 99 + j)] for j in range(4)]

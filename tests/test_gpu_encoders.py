@@ -130,3 +130,77 @@ def test_paired_encoders_equal_separate_calls(eng, prec):
         torch.cuda.synchronize()
         assert torch.equal(a1, a2), f"audio differs by {(a1 - a2).abs().max().item()}"
         assert torch.equal(t1, t2), f"text differs by {(t1 - t2).abs().max().item()}"
+
+
+@pytest.mark.parametrize("B,S,H,G", [(2, 199, 768, 16), (3, 149, 768, 16), (1, 17, 768, 16), (2, 224, 768, 16), (2, 225, 768, 16),
+                                     (1, 352, 768, 16), (2, 124, 1024, 16), (1, 224, 1024, 16)])
+def test_positional_conv_resident_slab_kernel(eng, B, S, H, G):
+    """The one-kernel positional conv (csrc/posconv.hip: the (clip, group) slab resident in LDS, weights streamed) against the
+    sliding-window GEMM it replaces and against a float64 evaluation of the same hi / lo split operands.  Same products
+    in the same order per accumulator: most outputs are identical, the rest one ulp apart, and both paths sit equally close
+    to the float64 value.  48- and 64-channel groups (Base / Large widths), frame counts on both sides of the 224-frame
+    variant and at its limits, odd frame counts."""
+    import ctypes as C
+    E, L = eng
+    fn = L.lib.ser_debug_posconv
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]
+    K, Cg = 128, H // G
+    g = torch.Generator().manual_seed(S + H)
+    z = torch.randn(B, S, H, generator=g).cuda()
+    wl = torch.randn(G * Cg, K, Cg, generator=g) * 0.02
+    w_il = L.split_bf16_il(torch.nn.functional.pad(wl, (0, 64 - Cg)).reshape(G * Cg, K * 64).cuda())
+    bias = torch.randn(H, generator=g).cuda()
+    slab = torch.zeros(B * G * (S + K - 1) * 128 + K * 128 + 64, dtype=torch.bfloat16, device="cuda")
+    outs = []
+    for direct in (0, 1):
+        out = torch.full((B, S, H), float("nan"), device="cuda")
+        L.check(fn(z.data_ptr(), w_il.data_ptr(), bias.data_ptr(), out.data_ptr(), B, S, H, G, K, direct, slab.data_ptr(), L.stream_ptr()),
+                "ser_debug_posconv")
+        torch.cuda.synchronize()
+        outs.append(out)
+    gemm, direct = outs
+    assert torch.isfinite(direct).all()
+    ulp = torch.finfo(torch.float32).eps * gemm.abs().clamp_min(1.0)
+    assert ((gemm - direct).abs() <= 2 * ulp).all(), f"differs from the GEMM path by {(gemm - direct).abs().max().item()}"
+    assert (gemm == direct).float().mean().item() > 0.6
+    # float64 value of the same split operands
+    hi, lo = L.il_planes(w_il)
+    W = (hi.double() + lo.double()).reshape(G, Cg, K, 64)[..., :Cg]
+    zh, zl = L.il_planes(L.split_bf16_il(z.reshape(B * S, H).contiguous()))
+    pad = torch.zeros(B, S + K - 1, H, dtype=torch.float64, device="cuda")
+    pad[:, K // 2:K // 2 + S] = (zh.double() + zl.double()).reshape(B, S, H)
+    ref = torch.empty(B, S, H, dtype=torch.float64, device="cuda")
+    for gi in range(G):
+        win = pad[:, :, gi * Cg:(gi + 1) * Cg].unfold(1, K, 1)[:, :S]                  # [B, S, Cg, K]
+        ref[:, :, gi * Cg:(gi + 1) * Cg] = torch.einsum("bsck,nkc->bsn", win, W[gi])
+    pre = ref + bias.double()
+    want = 0.5 * pre * (1 + torch.erf(pre / 2 ** 0.5)) + z.double()
+    e_gemm, e_direct = (gemm.double() - want).abs().max().item(), (direct.double() - want).abs().max().item()
+    assert e_direct < 5e-5 and e_direct < 1.05 * e_gemm + 1e-7, (e_gemm, e_direct)
+
+
+@pytest.mark.parametrize("samples", [64000, 40000])
+def test_wav2vec2_base_width_forward_with_resident_positional_conv(eng, samples):
+    """Base-width encoder (768-d, 16 groups of 48 channels, kernel 128): the engine takes the resident-slab kernel; the
+    output matches the oracle and the GEMM-path output to rounding."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    E, L = eng
+    L.lib.ser_debug_set_posconv_gemm.argtypes = [L.i32]
+    torch.manual_seed(5)
+    wc = Wav2Vec2Config(hidden_size=768, num_hidden_layers=1, num_attention_heads=12, intermediate_size=256,
+                        conv_dim=[64] * 6 + [32], num_conv_pos_embeddings=128, num_conv_pos_embedding_groups=16)
+    sd = {k: v.detach() for k, v in Wav2Vec2Model(wc).state_dict().items()}
+    e = E.Wav2Vec2Engine(wc, sd, "cuda", L.PREC_BF16X3)
+    waves = 0.1 * torch.randn(2, samples)
+    try:
+        L.lib.ser_debug_set_posconv_gemm(1)
+        ref = e.forward(waves.cuda()).clone()
+    finally:
+        L.lib.ser_debug_set_posconv_gemm(0)
+    got = e.forward(waves.cuda())
+    assert (ref - got).abs().max().item() < 2e-5
+    cfg = O.wav2vec2_config(hidden=768, layers=1, heads=12, ffn=256, conv_dim=wc.conv_dim, conv_kernel=wc.conv_kernel,
+                            conv_stride=wc.conv_stride, pos_kernel=128, pos_groups=16, eps=wc.layer_norm_eps)
+    want = O.wav2vec2_forward(sd, torch.stack([O.normalise_waveform(w) for w in waves]), cfg)
+    assert (got.cpu() - want).abs().max().item() < 3e-4
