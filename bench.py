@@ -232,6 +232,8 @@ def main():
             L.lib.ser_debug_set_gemm_stages_tall(*st[4:])
     if os.environ.get("SER_GEMM_LDS_PAD"):
         L.lib.ser_debug_set_gemm_lds_pad(int(os.environ["SER_GEMM_LDS_PAD"]))
+    if os.environ.get("SER_ATTN_VARIANT"):          # A/B: 1 = resident K and V (148 KB of LDS), 2 = K and V in turns (75 KB, default)
+        L.lib.ser_debug_set_attention_small_variant(int(os.environ["SER_ATTN_VARIANT"]))
     if os.environ.get("SER_POSCONV_GEMM"):          # A/B: the positional conv through the sliding-window GEMM instead of posconv.hip
         L.lib.ser_debug_set_posconv_gemm(int(os.environ["SER_POSCONV_GEMM"]))
     if os.environ.get("SER_GEMM_PERSIST"):

@@ -412,6 +412,240 @@ SER_DEVFN void attn_small_body(const AttnProb& P, const int head, const int b, c
   }
 }
 
+// ---- the same kernel with HALF the LDS footprint (two workgroups per CU, or one beside a GEMM workgroup of the other
+// stream): K and V take turns in one region.  Phase A: every wave computes the scores and the softmax of ALL its query
+// blocks (at most two) while K is resident - the probabilities stay in registers (2 x 56 VGPRs); barrier; phase B: V, which
+// every thread fetched into registers at the very start, replaces K in LDS; barrier; phase C: P.V and the output, staged
+// per 32-column half through a 2 KB tile per wave.  Products and their order per accumulator are those of
+// attn_small_body: results are bit-identical (tests/test_gpu_ops.py).
+template <bool X3>
+struct Sa2Cfg {
+  static constexpr int RB = SaCfg<X3>::RB;
+  static constexpr int OT = 16 * (RB / 2);                        // per-wave output tile: 16 rows x one 32-column half
+  static constexpr int LDS_BYTES = SA_MAXKEYS * RB + 1024 + SA_WAVES * OT;
+};
+
+template <bool X3>
+SER_DEVFN void attn_small2_body(const AttnProb& P, const int head, const int b, char* lds) {
+  constexpr int RB = SaCfg<X3>::RB, CH = SaCfg<X3>::CH, QPW = (SA_NKB + SA_WAVES - 1) / SA_WAVES;   // query blocks per wave
+  const int S = P.S, H = P.H;
+  const int nkb = (S + 15) >> 4;
+  const int nks = (nkb + 1) >> 1;
+  char* KV = lds;
+  float* kbias = (float*)(lds + SA_MAXKEYS * RB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* Os = lds + SA_MAXKEYS * RB + 1024 + wave * Sa2Cfg<X3>::OT;
+  const int fr = lane & 15, fq = lane >> 4;
+  const long long ld = 3LL * H;
+  const bool il_out = X3 && ser_is_il(P.ctx_hi, P.ctx_lo);
+  const int nrows = nks * 32;
+  constexpr int IT = (SA_MAXKEYS * CH + SA_WAVES * 64 - 1) / (SA_WAVES * 64);
+
+  // ---- K -> LDS, V -> registers (stored after phase A)
+  bf16x8 vreg[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = tid + it * SA_WAVES * 64, row = idx / CH, c = idx % CH;
+    bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0};
+    vreg[it] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (idx < nrows * CH && row < S) {
+      const long long base = ((long long)b * S + row) * ld + head * HD;
+      if (X3) {
+        kv = *(const bf16x8*)(P.qkv_hi + ser_il_off(base + H) + c * 8);
+        vreg[it] = *(const bf16x8*)(P.qkv_hi + ser_il_off(base + 2 * H) + c * 8);
+      } else {
+        kv = *(const bf16x8*)(P.qkv_hi + base + H + c * 8);
+        vreg[it] = *(const bf16x8*)(P.qkv_hi + base + 2 * H + c * 8);
+      }
+    }
+    if (idx < nrows * CH) *(bf16x8*)(KV + sa_off<X3>(row, c)) = kv;
+  }
+  for (int k = tid; k < 256; k += SA_WAVES * 64) {
+    bool ok = k < S;
+    if (ok && P.key_mask) ok = P.key_mask[(long long)b * S + k] != 0.f;
+    kbias[k] = ok ? 0.f : -INFINITY;
+  }
+  __syncthreads();
+
+  // ---- phase A: scores^T and softmax of my query blocks (sc[i][jb][r] = <K[16 jb + 4 fq + r], Q[qb*16 + fr]>)
+  f32x4 sc[QPW][SA_NKB];
+  float inv[QPW];
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int qb = wave + SA_WAVES * i;
+    inv[i] = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < SA_NKB; ++jb) sc[i][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (qb < nkb) {
+      bf16x8 qh[2], ql[2];
+      {
+        int qr = qb * 16 + fr;
+        qr = qr < S ? qr : S - 1;
+        const long long base = ((long long)b * S + qr) * ld + head * HD;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          if (X3) {
+            const long long e = ser_il_off(base + ks * 32 + fq * 8);
+            qh[ks] = *(const bf16x8*)(P.qkv_hi + e);
+            ql[ks] = *(const bf16x8*)(P.qkv_hi + e + SER_IL_GROUP);
+          } else {
+            qh[ks] = *(const bf16x8*)(P.qkv_hi + base + ks * 32 + fq * 8);
+          }
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < SA_NKB; ++jb) {
+        if (jb < nkb) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kh = *(const bf16x8*)(KV + sa_off<X3>(jb * 16 + fr, sa_chunk<X3>(0, ks * 4 + fq)));
+            if (X3) {
+              const bf16x8 kl = *(const bf16x8*)(KV + sa_off<X3>(jb * 16 + fr, sa_chunk<X3>(1, ks * 4 + fq)));
+              sc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, ql[ks], sc[i][jb], 0, 0, 0);
+              sc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qh[ks], sc[i][jb], 0, 0, 0);
+            }
+            sc[i][jb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qh[ks], sc[i][jb], 0, 0, 0);
+          }
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jb = 0; jb < SA_NKB; ++jb)
+        if (jb < nkb) {
+          const float4 kb4 = *(const float4*)(kbias + jb * 16 + fq * 4);
+          sc[i][jb][0] = sc[i][jb][0] * 0.125f + kb4.x;
+          sc[i][jb][1] = sc[i][jb][1] * 0.125f + kb4.y;
+          sc[i][jb][2] = sc[i][jb][2] * 0.125f + kb4.z;
+          sc[i][jb][3] = sc[i][jb][3] * 0.125f + kb4.w;
+          mx = fmaxf(mx, fmaxf(fmaxf(sc[i][jb][0], sc[i][jb][1]), fmaxf(sc[i][jb][2], sc[i][jb][3])));
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mu = mx == -INFINITY ? 0.f : mx;
+      float sum = 0.f;
+#pragma unroll
+      for (int jb = 0; jb < SA_NKB; ++jb)
+        if (jb < nkb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __expf(sc[i][jb][r] - mu);
+            sc[i][jb][r] = pv;
+            sum += pv;
+          }
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      inv[i] = sum > 0.f ? 1.0f / sum : 0.f;
+    }
+  }
+  __syncthreads();                 // every wave is done with K
+
+  // ---- phase B: V replaces K
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int idx = tid + it * SA_WAVES * 64, row = idx / CH, c = idx % CH;
+    if (idx < nrows * CH) *(bf16x8*)(KV + sa_off<X3>(row, c)) = vreg[it];
+  }
+  __syncthreads();
+
+  // ---- phase C: O = P . V (key permutation as in attn_small_body), output per 32-column half
+  const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int qb = wave + SA_WAVES * i;
+    if (qb >= nkb) continue;
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < SA_NKB / 2; ++ks) {
+      if (ks < nks) {
+        uint32_t ph[4], pl[4];
+        const f32x4 p0 = sc[i][2 * ks], p1 = sc[i][2 * ks + 1];
+        if (X3) {
+          split_bf16x2(p0[0] * inv[i], p0[1] * inv[i], ph[0], pl[0]);
+          split_bf16x2(p0[2] * inv[i], p0[3] * inv[i], ph[1], pl[1]);
+          split_bf16x2(p1[0] * inv[i], p1[1] * inv[i], ph[2], pl[2]);
+          split_bf16x2(p1[2] * inv[i], p1[3] * inv[i], ph[3], pl[3]);
+        } else {
+          ph[0] = pack_bf16x2(p0[0] * inv[i], p0[1] * inv[i]);
+          ph[1] = pack_bf16x2(p0[2] * inv[i], p0[3] * inv[i]);
+          ph[2] = pack_bf16x2(p1[0] * inv[i], p1[1] * inv[i]);
+          ph[3] = pack_bf16x2(p1[2] * inv[i], p1[3] * inv[i]);
+        }
+        const bf16x8 pah = __builtin_bit_cast(bf16x8, make_uint4(ph[0], ph[1], ph[2], ph[3]));
+        bf16x8 pal;
+        if (X3) pal = __builtin_bit_cast(bf16x8, make_uint4(pl[0], pl[1], pl[2], pl[3]));
+        const int r0 = ks * 32 + fq * 4 + tq, r1 = r0 + 16;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const int dc = db * 2 + (tp >> 1), hb = (tp & 1) * 8;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(KV + sa_off<X3>(r0, sa_chunk<X3>(0, dc)) + hb));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(KV + sa_off<X3>(r1, sa_chunk<X3>(0, dc)) + hb));
+          const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          if (X3) {
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(KV + sa_off<X3>(r0, sa_chunk<X3>(1, dc)) + hb));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(KV + sa_off<X3>(r1, sa_chunk<X3>(1, dc)) + hb));
+            const bf16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pal, vh, o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pah, vl, o[db], 0, 0, 0);
+          }
+          o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pah, vh, o[db], 0, 0, 0);
+        }
+      }
+    }
+    // output block [16 q][64 d], one 32-column half at a time: tile row = [hi 32 | lo 32] (X3) or [32 values]
+    constexpr int HB = RB / 2;                                   // bytes of a half row in the tile and in the global row
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        const int db = hf * 2 + dd;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = fq * 4 + r, dloc = dd * 16 + fr;           // column inside the half
+          bf16_t h, lo_;
+          split_bf16(o[db][r], h, lo_);
+          *(bf16_t*)(Os + row * HB + dloc * 2) = h;
+          if (X3) *(bf16_t*)(Os + row * HB + 64 + dloc * 2) = lo_;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      constexpr int CPR = HB / 16;                               // 16-byte chunks per half row
+#pragma unroll
+      for (int it = 0; it < 16 * CPR / 64; ++it) {
+        const int idx = lane + 64 * it, row = idx / CPR, c = idx % CPR;
+        const int q = qb * 16 + row;
+        if (q < S) {
+          const uint4 v = *(const uint4*)(Os + row * HB + c * 16);
+          const long long base = ((long long)b * S + q) * H + head * HD;
+          if (X3) {
+            if (il_out) {
+              *(uint4*)(P.ctx_hi + ser_il_off(base) + hf * 64 + c * 8) = v;
+            } else {                                             // planar planes: chunks 0-3 = hi, 4-7 = lo of columns 32 hf ..
+              *(uint4*)(((c >> 2) ? P.ctx_lo : P.ctx_hi) + base + hf * 32 + (c & 3) * 8) = v;
+            }
+          } else {
+            *(uint4*)(P.ctx_hi + base + hf * 32 + c * 8) = v;
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();                           // the tile is reused by the next half / query block
+    }
+  }
+}
+
+template <bool X3>
+__global__ __launch_bounds__(SA_WAVES * 64) void self_attention_small2_kernel(const AttnProb P0, const AttnProb P1, const int n0,
+                                                                                const int heads) {
+  __shared__ __attribute__((aligned(1024))) char lds[Sa2Cfg<X3>::LDS_BYTES];
+  const int blk = blockIdx.x;
+  if (blk < n0) attn_small2_body<X3>(P0, blk % heads, blk / heads, lds);
+  else attn_small2_body<X3>(P1, (blk - n0) % heads, (blk - n0) / heads, lds);
+}
+
 // one or two problems (same clip count and head count) in one launch; the (clip, head) blocks of problem 0 come first
 template <bool X3>
 __global__ __launch_bounds__(SA_WAVES * 64) void self_attention_small_kernel(const AttnProb P0, const AttnProb P1, const int n0,
@@ -429,6 +663,8 @@ static bool small_ok(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* c
   return !x3 || ser_is_il(qkv_hi, qkv_lo);
 }
 static int g_attn_force_generic = 0;      // tests: run the chunked kernel on shapes the resident kernel would take
+static int g_attn_small_variant = 2;      // 2: K and V share one LDS region (two workgroups per CU); 1: both resident
+extern "C" int ser_debug_set_attention_small_variant(int v) { g_attn_small_variant = v; return 0; }
 extern "C" int ser_debug_set_attention_generic(int on) { g_attn_force_generic = on; return 0; }
 
 template <bool X3>
@@ -458,7 +694,10 @@ int ser_launch_self_attention_pair(const SerAttnArgs& a, const SerAttnArgs& b, h
     const int Hh = a.heads * HD, n0 = a.B * a.heads;
     const AttnProb Q0{a.qkv_hi, x3 ? a.qkv_lo : nullptr, a.key_mask, a.S, Hh, a.ctx_hi, x3 ? a.ctx_lo : nullptr};
     const AttnProb Q1{b.qkv_hi, x3 ? b.qkv_lo : nullptr, b.key_mask, b.S, Hh, b.ctx_hi, x3 ? b.ctx_lo : nullptr};
-    if (x3) hipLaunchKernelGGL(self_attention_small_kernel<true>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
+    if (g_attn_small_variant == 2) {
+      if (x3) hipLaunchKernelGGL(self_attention_small2_kernel<true>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
+      else hipLaunchKernelGGL(self_attention_small2_kernel<false>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
+    } else if (x3) hipLaunchKernelGGL(self_attention_small_kernel<true>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
     else hipLaunchKernelGGL(self_attention_small_kernel<false>, dim3(2 * n0), dim3(SA_WAVES * 64), 0, st, Q0, Q1, n0, a.heads);
     SER_LAUNCH_CHECK();
     return SER_OK;
@@ -481,7 +720,10 @@ int ser_launch_self_attention(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const 
   if (!g_attn_force_generic && small_ok(qkv_hi, qkv_lo, ctx_lo, S)) {
     const bool x3 = qkv_lo && ctx_lo;
     const AttnProb Q{qkv_hi, x3 ? qkv_lo : nullptr, key_mask, S, H, ctx_hi, x3 ? ctx_lo : nullptr};
-    if (x3) hipLaunchKernelGGL(self_attention_small_kernel<true>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
+    if (g_attn_small_variant == 2) {
+      if (x3) hipLaunchKernelGGL(self_attention_small2_kernel<true>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
+      else hipLaunchKernelGGL(self_attention_small2_kernel<false>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
+    } else if (x3) hipLaunchKernelGGL(self_attention_small_kernel<true>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
     else hipLaunchKernelGGL(self_attention_small_kernel<false>, dim3(B * heads), dim3(SA_WAVES * 64), 0, st, Q, Q, B * heads, heads);
     SER_LAUNCH_CHECK();
     return SER_OK;

@@ -191,3 +191,46 @@ def test_self_attention_resident_one_plane(L, S, masked):
         assert (ch.float().cpu().double() - ref).abs().max().item() < 2e-2
         outs.append(ch.float().cpu())
     assert (outs[0] - outs[1]).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("S,masked", [(199, False), (199, True), (32, True), (149, True), (224, False), (17, True), (1, False)])
+@pytest.mark.parametrize("mode", ["interleaved", "one-plane", "planar-out"])
+def test_self_attention_half_footprint_kernel_is_bit_identical(L, S, masked, mode):
+    """The default resident kernel lets K and V take turns in one LDS region (scores and softmax of all of a wave's query
+    blocks first, then V replaces K): same products in the same order as the form that keeps both resident, so the planes
+    it writes are identical bit for bit, in every plane layout."""
+    L.lib.ser_debug_set_attention_small_variant.argtypes = [L.i32]
+    B, heads = 3, 4
+    H = heads * 64
+    qkv = _rand(B * S, 3 * H, seed=31 + S)
+    mk = None
+    if masked:
+        mask = torch.ones(B, S)
+        mask[1, max(0, S - 5):] = 0
+        if S > 9:
+            mask[2, 3:9] = 0
+        mk = mask.cuda()
+    outs = []
+    for variant in (1, 2):
+        L.lib.ser_debug_set_attention_small_variant(variant)
+        try:
+            if mode == "interleaved":
+                q_il = L.split_bf16_il(qkv.cuda())
+                c = torch.full((B * S, 2 * H), -1.0, dtype=torch.bfloat16, device="cuda")
+                L.check(L.lib.ser_self_attention(*L.il_ptrs(q_il), L.ptr(mk), B, S, heads, *L.il_ptrs(c), L.stream_ptr()))
+                res = (c,)
+            elif mode == "one-plane":
+                qh, _ = L.split_bf16(qkv.cuda(), False)
+                res = (L.self_attention(qh, None, mk, B, S, heads)[0],)
+            else:                      # interleaved input, planar output planes
+                q_il = L.split_bf16_il(qkv.cuda())
+                ch = torch.full((B * S, H), -1.0, dtype=torch.bfloat16, device="cuda")
+                cl = torch.full((B * S, H), -1.0, dtype=torch.bfloat16, device="cuda")
+                L.check(L.lib.ser_self_attention(*L.il_ptrs(q_il), L.ptr(mk), B, S, heads, ch.data_ptr(), cl.data_ptr(), L.stream_ptr()))
+                res = (ch, cl)
+            torch.cuda.synchronize()
+        finally:
+            L.lib.ser_debug_set_attention_small_variant(2)
+        outs.append([r.clone() for r in res])
+    for a, b_ in zip(*outs):
+        assert torch.equal(a.view(torch.int16), b_.view(torch.int16)), f"differs by {(a.float() - b_.float()).abs().max().item()}"
