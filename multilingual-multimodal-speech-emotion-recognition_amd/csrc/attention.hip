@@ -8,6 +8,7 @@
 // ds_read_b128 fragment read is bank-conflict free.  P goes through a per-wave LDS tile to turn
 // the MFMA C layout (key on the lane) into the A layout (key along k).
 #include "ser_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -663,7 +664,11 @@ static bool small_ok(const bf16_t* qkv_hi, const bf16_t* qkv_lo, const bf16_t* c
   return !x3 || ser_is_il(qkv_hi, qkv_lo);
 }
 static int g_attn_force_generic = 0;      // tests: run the chunked kernel on shapes the resident kernel would take
-static int g_attn_small_variant = 2;      // 2: K and V share one LDS region (two workgroups per CU); 1: both resident
+static int attn_variant_default() {
+  const char* e = getenv("SER_ATTN_VARIANT");
+  return e && e[0] == '1' ? 1 : 2;
+}
+static int g_attn_small_variant = attn_variant_default();      // 2: K and V share one LDS region (two workgroups per CU); 1: both resident
 extern "C" int ser_debug_set_attention_small_variant(int v) { g_attn_small_variant = v; return 0; }
 extern "C" int ser_debug_set_attention_generic(int on) { g_attn_force_generic = on; return 0; }
 
