@@ -592,7 +592,13 @@ class PipelinedStepper:
         self._loose_grads = [(p, p.grad) for grp, segs, loose in self.opt._plan for p in loose if p.grad is not None]
         self._pick_encoder_stream()
         if self.refine_plans:
-            self.refine_gemm_plans()
+            try:
+                self.refine_gemm_plans()
+            except Exception as e:      # noqa: BLE001 - a tuning extra must not take the step down: keep the stand-alone plans
+                import sys
+                sys.stderr.write(f"PipelinedStepper: in-situ plan refinement skipped ({type(e).__name__}: {e})\n")
+                self._capture_encoders()
+                self._reset_grads_after_idle_replays()
 
     def _capture_encoders(self):
         s = self.sys
