@@ -150,7 +150,7 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def gemm_plans(args, wc):
+def gemm_plans(args, wc, group=1):
     """Tile configuration the engines' timing pass recorded for the four layer GEMMs of this run (SER_GEMM_CFG_* ids: rows
     of a BM x 128 tile, 3xxx single-buffer, 7xxx BM x 64, 1xxx / 2xxx / 5xxx / 6xxx 512-thread tiles)."""
     import ctypes as C
@@ -162,7 +162,7 @@ def gemm_plans(args, wc):
         T = int(16000 * args.seconds)
         for k, st in zip(wc.conv_kernel, wc.conv_stride):
             T = (T - k) // st + 1
-        rows = args.batch * T + args.batch * args.tokens
+        rows = group * (args.batch * T + args.batch * args.tokens)
         H, F = wc.hidden_size, wc.intermediate_size
         out = {}
         for name, N, K in (("qkv", 3 * H, H), ("oproj", H, H), ("ffn1", F, H), ("ffn2", H, F)):
@@ -189,8 +189,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run encoders and head back to back instead of encoder(t+1) beside head(t)")
-    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
-                    help="frozen-encoder passes in flight beside the head step: 1 = batch t+1, 2 = batches t+1 and t+2 (two encoder graphs)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="consecutive batches whose frozen-encoder forward is issued as ONE pass (rows of all of them in every GEMM launch) "
+                         "beside the head steps of the previous group; every batch still gets exactly one encoder pass and one update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -236,8 +237,12 @@ def main():
         L.lib.ser_debug_set_attention_small_variant(int(os.environ["SER_ATTN_VARIANT"]))
     if os.environ.get("SER_POSCONV_GEMM"):          # A/B: the positional conv through the sliding-window GEMM instead of posconv.hip
         L.lib.ser_debug_set_posconv_gemm(int(os.environ["SER_POSCONV_GEMM"]))
+    if os.environ.get("SER_GEMM_OCC"):            # A/B: encoder-GEMM occupancy headroom in percent (default set below)
+        L.lib.ser_set_gemm_occupancy_pct(int(os.environ["SER_GEMM_OCC"]))
     if os.environ.get("SER_GEMM_PERSIST"):
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
+    if os.environ.get("SER_HEAD_PRIORITY"):       # A/B: step on a stream of this priority (-1 = high) instead of the default stream
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["SER_HEAD_PRIORITY"])))
     sysm, wc, xc = build_system(args.precision, dev, stress=args.stress, unfreeze=args.unfreeze)
     sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
     if args.unfreeze:                              # the encoders' own training-mode noise, as the reference's .train() gives it
@@ -245,6 +250,7 @@ def main():
             m.encoder_train_noise, m.noise_seed = True, rank
     sysm.train()
     sample = None
+    from ser_amd import _engines as E
     if rank == 0 and not args.no_cpu_baseline:
         sample = parity_sample(sysm, xc, args, dev)      # on the initial weights, before any optimizer step
     opt = sysm.make_optimizer(lr=1e-4)
@@ -260,8 +266,8 @@ def main():
     pipeline = use_graph and not args.no_pipeline and not args.unfreeze     # unfrozen encoders depend on the last update: no overlap across steps
     if pipeline:
         from ser_amd.system import PipelinedStepper
-        stepper = PipelinedStepper(sysm, opt, None, reducer, depth=args.depth)
-        for j in range(args.depth):     # encoders of the first batch(es); every step() then does one encoder pass + one update
+        stepper = PipelinedStepper(sysm, opt, None, reducer, group=args.group)
+        for j in range(stepper.prime):  # two groups in flight before the first step; every step() then stages one batch and trains on one
             stepper.feed(*batches[j % 4])
     it = 0
     for _ in range(max(1, args.warmup)):
@@ -298,13 +304,21 @@ def main():
     # ---- roofline leg: HIP events around every launch of the dominant kernel (the encoder MFMA GEMM) -------
     roof = None
     if rank == 0:
-        eager = TrainStepper(sysm, opt, None, None, use_graph=False)
         prof_start, prof_stop = (L.lib.ser_prof_gemm_f32_start, L.lib.ser_prof_gemm_f32_stop) if args.unfreeze \
             else (L.lib.ser_prof_gemm_start, L.lib.ser_prof_gemm_stop)
-        L.check(prof_start())
         nprof = 3
-        for _ in range(nprof):
-            eager.step(*batch)
+        L.check(prof_start())
+        if pipeline:
+            # the launches the timed region replays from its graphs - one encoder pass over `group` batches - issued eagerly
+            # on the encoder stream with a HIP event pair around every GEMM launch, BESIDE head-graph replays on the main
+            # stream as in the timed schedule (events cannot be recorded inside a replayed graph)
+            stepper.profile_encoder_passes(nprof)
+            steps_profiled = nprof * stepper.group
+        else:
+            eager = TrainStepper(sysm, opt, None, None, use_graph=False)
+            for _ in range(nprof):
+                eager.step(*batch)
+            steps_profiled = nprof
         ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
         prof_stop.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         L.check(prof_stop(C.byref(ms), C.byref(fl), C.byref(n)))
@@ -325,9 +339,13 @@ def main():
                     kernel=("gemm_x3_kernel / gemm_x3_group_kernel / gemm_f32_kernel (csrc/gemm_f32.hip: fp32 operands split to bf16 hi+lo on the fly; "
                             "forward, dgrad and wgrad products of encoders and head)" if args.unfreeze else
                             "gemm_bf16_nt_kernel + gemm_bf16_pair_kernel (same tile code; the pair form runs layer l of both encoders)"),
-                    launches_per_step=n.value // nprof,
+                    launches_per_step=round(n.value / steps_profiled, 2),
+                    launches_per_encoder_pass=n.value // nprof,
                     avg_launch_us=round(ms.value * 1e3 / max(1, n.value), 2),
-                    algorithmic_gflop_per_step=round(fl.value / nprof / 1e9, 1),
+                    algorithmic_gflop_per_step=round(fl.value / steps_profiled / 1e9, 1),
+                    gemm_ms_per_step=round(ms.value / steps_profiled, 4),
+                    measured=("HIP events around every launch of one encoder pass issued eagerly on the encoder stream beside head-graph "
+                              "replays (the timed schedule's overlap)" if pipeline else "HIP events around every launch of eager steps"),
                     mfma_products_per_mac=nprod,
                     note=("achieved / frac count algorithmic FLOPs (2 M N K); the parity mode executes mfma_products_per_mac bf16 MFMA "
                           "products per multiply, so the matrix pipes run at mfma_pipe_utilisation = products x frac of the dense bf16 "
@@ -361,16 +379,17 @@ def main():
                                      "bf16x3: operands split into bf16 hi+lo planes, 3 bf16 MFMA products per multiply, fp32 accumulate"
                                      if args.precision == "bf16x3" else "bf16: 1 bf16 MFMA product per multiply, fp32 accumulate (fast mode, no 1e-3 parity claim)"),
                        "parallelism": "dp%d" % world, "launch": "hipGraph" if use_graph else "eager",
-                       "schedule": (("frozen-encoder forward of batch t+1 overlapped with head fwd/bwd/AdamW of batch t "
-                                     "(two streams; one encoder pass and one update per step)") if args.depth == 1 else
-                                    ("frozen-encoder forwards of batches t+1 and t+2 in flight (two encoder graphs, two streams, own "
-                                     "workspaces) beside head fwd/bwd/AdamW of batch t; one encoder pass and one update per step"))
+                       "schedule": (("frozen-encoder forward of %d consecutive batches issued as ONE pass (%d clips per GEMM launch) on a second "
+                                     "stream, beside the head fwd/bwd/AdamW steps of the previous group; every batch goes through exactly one "
+                                     "encoder pass and one update, bit-identical to sequential stepping") % (args.group, args.group * args.batch))
                                    if pipeline else "sequential",
+                       "encoder_group": args.group if pipeline else 1,
                        "stress_sizes": bool(args.stress),
                        "allreduce_overlap": (None if world == 1 else
-                                             ("classifier bucket (76 of 100 MB) all-reduced over RCCL beside the backward of fusion / pooling / "
-                                              "cross-attention / adapters (head graph captured in two pieces), the rest before AdamW"
-                                              if getattr(stepper, "split", False) else "all buckets reduced after backward (no overlap)")),
+                                             (("classifier bucket (76 of 100 MB) all-reduced over %s beside the backward of fusion / pooling / "
+                                               "cross-attention / adapters (head graph captured in two pieces), the rest before AdamW"
+                                               if getattr(stepper, "split", False) else "all buckets reduced over %s after backward (no overlap)")
+                                              % ("RCCL (backend nccl)" if dist.get_backend() == "nccl" else "backend " + dist.get_backend()))),
                        "head_dropout": ("training mode (77 nn.Dropout sites of the head + the encoders' HF dropout sites, LayerDrop and SpecAugment)"
                                         if args.unfreeze else "training mode (77 nn.Dropout sites active; frozen encoders in eval semantics)")},
             "roofline": roof, "cpu_baseline": cpu,
@@ -378,8 +397,7 @@ def main():
             "parity_on": "initial weights, before the first optimizer step", "oracle_logit_spread_across_clips": spread,
             "whole_step_algorithmic_tflops": None if step_tflops is None else round(step_tflops, 2),
             "loss": round(loss, 5),
-            "gemm_plans": gemm_plans(args, wc),
-            "gemm_plan_refinements_in_situ": [list(r) for r in getattr(stepper, "plan_refinements", [])],
+            "gemm_plans": gemm_plans(args, wc, args.group if pipeline else 1),
         }
         print(json.dumps(out))
     if world > 1:

@@ -430,6 +430,48 @@ int ser_resample(const float* x, int B, int T, int orig_freq, int new_freq, int 
 int ser_add_noise_snr(const float* x, int B, int T, const float* snr_db, unsigned long long seed, float* sigma, float* y,
                       void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * tuning and diagnostics (process-wide settings; none changes a result: every tile configuration
+ * sums k in the same order per accumulator, tests/test_gpu_interleaved.py).  No reference
+ * counterpart: the reference leaves kernel selection to torch / hipBLASLt.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Tile plan of the encoder GEMM for one shape (rows over all batch entries, N, K; three_products = interleaved
+ * split-bf16 operands): cfg = SER_GEMM_CFG_* (64..192 = rows of a BM x 128 tile, 3xxx single LDS buffer, 7xxx BM x 64,
+ * 1xxx/2xxx/5xxx/6xxx 512-thread tiles), ksplit = split-K factor.  Filled by the engines' timing pass
+ * (_engines.tune_gemm_shapes); shapes without a plan use the library's cost model. */
+int ser_gemm_plan_set(long long rows_total, int N, int K, int three_products, int cfg, int ksplit);
+int ser_gemm_plan_get(long long rows_total, int N, int K, int three_products, int* cfg, int* ksplit);
+/* Occupancy headroom: an encoder GEMM launches at most pct % of the workgroup slots its tile configuration could hold
+ * resident and walks its tiles grid-stride, so the head kernels of the other queues find free slots. */
+int ser_set_gemm_occupancy_pct(int pct);
+int ser_get_gemm_occupancy_pct(void);
+
+/* experiment / test knobs (scripts/, tests/): force a tile configuration, LDS pipeline depths, extra dynamic LDS, a
+ * persistent grid cap, kernel variants; stand-alone probes of single kernels */
+int ser_debug_set_gemm_bm(int cfg);
+int ser_debug_set_gemm_stages(int s128, int s64x128, int s64, int s128x64);
+int ser_debug_set_gemm_stages_tall(int s96, int s160, int s192);
+int ser_debug_set_gemm_lds_pad(int bytes);
+int ser_debug_set_gemm_persist(int cap);
+int ser_debug_set_attention_small_variant(int v);
+int ser_debug_set_attention_generic(int on);
+int ser_debug_set_posconv_gemm(int on);
+int ser_debug_set_pair_mask(int m);
+int ser_debug_set_f32_bk(int bk);
+int ser_debug_set_head_x3(int v);
+int ser_debug_set_dgrad16(int v);
+int ser_debug_gemm_pair(const uint16_t* a0, const uint16_t* w0, int M0, int N0, int K0, float* c0, const uint16_t* a1,
+                        const uint16_t* w1, int M1, int N1, int K1, float* c1, void* stream);
+int ser_debug_gemm_batched(const uint16_t* a, const uint16_t* w, int M, int N, int K, int nb, long long sa, long long sw,
+                           uint16_t* c, long long sc, int il, void* stream);
+int ser_debug_gemm_il_cfg(const uint16_t* a, const uint16_t* w, int M, int N, int K, int cfg, int ksplit, float* c_f32,
+                          void* stream);
+int ser_debug_posconv(const float* z, const uint16_t* w_il, const float* bias, float* out, int B, int S, int H, int G, int K,
+                      int direct, uint16_t* slab_il, void* stream);
+int ser_debug_barrier_probe(int G, int rounds, int mode, void* flags, void* data, void* errors, void* stream);
+int ser_debug_stack_timeline(void* buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -220,17 +220,32 @@ _SKIP_CFG_FAMILIES = {int(x) for x in os.environ.get("SER_GEMM_SKIP_FAMILIES", "
 TILE_CONFIGS_X3 = TILE_HEIGHTS + (3064, 3096, 3128, 1192, 1256, 5128, 6256, 7064, 7096, 7128, 7192)
 
 
-def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def tune_gemm_shapes(shapes, device, reps=8, three_products=False, collective=False):
     """shapes: iterable of (rows_total, N, K) of bf16 NT GEMMs with N >= 128; `three_products`: the interleaved
-    three-product mode (its own table: a k-tile carries 1.5x the MFMA work of the one-product kernel's)."""
+    three-product mode (its own table: a k-tile carries 1.5x the MFMA work of the one-product kernel's).
+
+    Data parallel (world > 1): timings differ from GPU to GPU, and a rank on a slower plan sets the pace of every step,
+    so plans must be the same everywhere.  The LAZY call from a forward is then a no-op (ranks reach it with different
+    batch shapes - ragged and partial batches - so it cannot be a collective; the library's cost model picks the tiles,
+    identically on every rank).  `collective=True` is the explicit form for a point every rank reaches with the same
+    shapes (PipelinedStepper's capture): all ranks time, rank 0's choices are broadcast and installed everywhere."""
     if torch.cuda.is_current_stream_capturing():
         return
+    if _world() > 1 and not collective:
+        return
     pm = 2 if three_products else 1
+    fresh = []
     for rows, N, K in shapes:
         key = (int(rows), int(N), int(K), pm, torch.device(device).index)
         if key in _TUNED or N < 128 or rows <= 64:
             continue
         _TUNED.add(key)
+        fresh.append((int(rows), int(N), int(K)))
         g = torch.Generator(device="cpu").manual_seed(0)     # random operands: zeros flatter the clock (DVFS)
         a = (torch.randn(rows, K * pm, generator=g) * 0.5).to(device=device, dtype=torch.bfloat16)
         w = (torch.randn(N, K * pm, generator=g) * 0.05).to(device=device, dtype=torch.bfloat16)
@@ -265,6 +280,25 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False):
             L.lib.ser_debug_set_gemm_bm(0)
         L.lib.ser_gemm_tile_hint_mode(rows, N, K, 1 if three_products else 0, best)
         _TUNE_RANKED[(int(rows), int(N), int(K), bool(three_products))] = sorted(ranked)
+    if collective:
+        _share_plans(fresh, three_products)
+
+
+def _share_plans(fresh, three_products):
+    """Rank 0's choices for the freshly timed shapes, installed on every rank (results are bit-identical under any plan;
+    this is about speed and about reproducible `gemm_plans` in the bench line).  Collective: every rank calls it with the
+    same shapes in the same order."""
+    import torch.distributed as dist
+    if not fresh or _world() < 2:
+        return
+    mine = [(k, _TUNE_RANKED[k + (bool(three_products),)][0][1]) for k in fresh]
+    box = [mine]
+    dist.broadcast_object_list(box, src=0)
+    for (rows, N, K), cfg in box[0]:
+        L.lib.ser_gemm_tile_hint_mode(rows, N, K, 1 if three_products else 0, int(cfg))
+        ranked = _TUNE_RANKED.get((rows, N, K, bool(three_products)))
+        if ranked is not None and ranked[0][1] != cfg:      # keep the local table consistent with what is installed
+            _TUNE_RANKED[(rows, N, K, bool(three_products))] = sorted(ranked, key=lambda r: (r[1] != cfg, r[0]))
 
 
 def close_runner_ups(margin=1.06, limit=2):
@@ -298,6 +332,13 @@ def _w2v_gemm_shapes(cfg, B, T, extra_rows=0):
     return shapes
 
 
+def tune_pair(a, t, B, T, Bt, St, collective=False):
+    """Timing pass for the GEMM shapes of one paired encoder call (B clips of T samples, Bt x St tokens)."""
+    if a.cfg.layers == t.cfg.layers and a.cfg.hidden == t.cfg.hidden:
+        tune_gemm_shapes(_w2v_gemm_shapes(a.cfg, B, T, extra_rows=Bt * St), a.device, three_products=a.prec == L.PREC_BF16X3,
+                         collective=collective)
+
+
 def forward_pair(audio_engine, text_engine, wave, ids, attn_mask, slot=0):
     """Both frozen encoders in ONE call on the current stream (ser_encoders_forward): when the two models have the
     same depth their layers run in lock-step with one launch per step for both.  -> (a_enc [B,S_a,H], t_enc [B,S_t,H])."""
@@ -319,8 +360,7 @@ def forward_pair(audio_engine, text_engine, wave, ids, attn_mask, slot=0):
     # slot > 0: a second workspace pair, for an encoder pass that runs beside another one (PipelinedStepper depth 2)
     wsa = (a.ws if slot == 0 else a.__dict__.setdefault('_ws_slots', {}).setdefault(slot, _Workspace())).get(na, wave.device)
     wst = (t.ws if slot == 0 else t.__dict__.setdefault('_ws_slots', {}).setdefault(slot, _Workspace())).get(nt, ids.device)
-    if a.cfg.layers == t.cfg.layers and a.cfg.hidden == t.cfg.hidden:
-        tune_gemm_shapes(_w2v_gemm_shapes(a.cfg, B, T, extra_rows=Bt * St), wave.device, three_products=a.prec == L.PREC_BF16X3)
+    tune_pair(a, t, B, T, Bt, St)
     out_a = torch.empty(B, Sa, a.hidden, dtype=torch.float32, device=wave.device)
     out_t = torch.empty(Bt, St, t.hidden, dtype=torch.float32, device=ids.device)
     L.check(L.lib.ser_encoders_forward(C.byref(a.cfg), C.byref(a.w), wave.data_ptr(), B, T, C.byref(t.cfg), C.byref(t.w),

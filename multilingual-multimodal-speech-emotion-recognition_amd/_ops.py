@@ -91,6 +91,47 @@ def wgrad_join():
         _WG["dirty"] = False
 
 
+# Independent branches of the head (text adapter, T<-A cross-attention direction, text pooling) may run on a second stream.
+# SIDE_STREAMS = False runs them inline on the caller's stream (same arithmetic either way).
+import os as _os
+SIDE_STREAMS = _os.environ.get("SER_SIDE_STREAMS", "1") == "1"
+
+
+class fork:
+    """with fork(side_stream) as f: <independent work>; then f.join(produced=[...], consumed=[...]).
+    On entry the side stream waits for the current one; `join` makes the current stream wait for the side stream and
+    records the cross-stream uses with the allocator (tensors produced on the side stream and used on the current one,
+    tensors of the current stream consumed on the side stream).  With SIDE_STREAMS off, or side=None, everything runs
+    inline and join is a no-op."""
+
+    def __init__(self, side):
+        self.side = side if SIDE_STREAMS else None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.cur = torch.cuda.current_stream()
+            self.side.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.side is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+    def join(self, produced=(), consumed=()):
+        if self.side is None:
+            return
+        self.cur.wait_stream(self.side)
+        for t in produced:
+            if t is not None:
+                t.record_stream(self.cur)
+        for t in consumed:
+            if t is not None:
+                t.record_stream(self.side)
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 

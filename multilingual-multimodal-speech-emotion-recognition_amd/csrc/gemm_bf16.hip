@@ -470,16 +470,21 @@ void gemm_bf16_nt_kernel(const SerGemmArgs g, const int tiles, const int total) 
 // large one instead of queueing, launch after launch, on a second stream behind it.
 template <int BM, int BN, int MODE, int NS = 2, int WR = 2, int WC = 2>
 __global__ __launch_bounds__((GemmCfg<BM, BN, MODE, NS, WR, WC>::NT), (GemmCfg<BM, BN, MODE, NS, WR, WC>::WAVES_PER_SIMD))
-void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0, const int tiles0, const int tiles1) {
+void gemm_bf16_pair_kernel(const SerGemmArgs g0, const SerGemmArgs g1, const int total0, const int tiles0, const int tiles1, const int total_all) {
   __shared__ __attribute__((aligned(1024))) char lds[GemmCfg<BM, BN, MODE, NS, WR, WC>::LDS_BYTES];
-  // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches
-  const bool first = (int)blockIdx.x < total0;
-  const SerGemmArgs* g = first ? &g0 : &g1;
   // total0 / tiles0 / tiles1 count (tile, split-K slice) pairs when the problems are split (both with the same factor)
   const int ks = g0.ksplit > 1 ? g0.ksplit : 1;
-  const int w = first ? blockIdx.x : blockIdx.x - total0, tiles = first ? tiles0 : tiles1;
-  const int t = w / ks;
-  gemm_tile<BM, BN, MODE, NS, WR, WC>(*g, t % tiles, t / tiles, lds, w % ks);
+  // grid-stride walk of the flattened (problem, batch entry, tile, slice) space: the grid may be smaller than the work
+  // (occupancy headroom, see launch_kernel); with one workgroup per item the loop runs once
+  for (int wi = blockIdx.x; wi < total_all; wi += gridDim.x) {
+    // one call site: the problem is chosen by (uniform) address, not by duplicating the tile code in two branches
+    const bool first = wi < total0;
+    const SerGemmArgs* g = first ? &g0 : &g1;
+    const int w = first ? wi : wi - total0, tiles = first ? tiles0 : tiles1;
+    const int t = w / ks;
+    gemm_tile<BM, BN, MODE, NS, WR, WC>(*g, t % tiles, t / tiles, lds, w % ks);
+    __syncthreads();     // the epilogue's LDS tile is dead before the next tile's first stage lands
+  }
 }
 
 // ---- optional per-launch timing with HIP events (bench.py roofline leg; off by default) ----------
@@ -489,6 +494,21 @@ struct ProfRec {
 };
 static int g_gemm_persist_cap = 0;   // 0 = one workgroup per tile; N = persistent grid of at most N workgroups
 extern "C" int ser_debug_set_gemm_persist(int cap) { g_gemm_persist_cap = cap; return 0; }
+// Occupancy headroom.  An encoder GEMM normally claims every workgroup slot of the chip (2-4 per CU); the head of the
+// previous batches runs beside it on other queues as ~150 small dependent kernels, and each of those then waits for a GEMM
+// workgroup to retire before it can be placed (measured: ~11 us per kernel boundary instead of 1.7, head step 2.75 -> 5.0 ms
+// - the head, not the encoders, became the critical path once one encoder pass covered several batches).  With
+// g_gemm_occupancy_pct = P < 100 a GEMM launches at most P % of the slots its tile configuration could hold resident and
+// walks its tiles grid-stride; the remaining slots stay free for the other queues for the whole launch.
+static int g_gemm_occupancy_pct = 100;
+extern "C" int ser_set_gemm_occupancy_pct(int pct) { g_gemm_occupancy_pct = pct < 10 ? 10 : (pct > 100 ? 100 : pct); return 0; }
+extern "C" int ser_get_gemm_occupancy_pct(void) { return g_gemm_occupancy_pct; }
+static int resident_cap(int wg_per_cu) {
+  if (g_gemm_occupancy_pct >= 100) return 0;                         // no cap
+  int cap = 256 * wg_per_cu * g_gemm_occupancy_pct / 100;
+  cap -= cap % 8;                                                    // blocks b, b + 8, ... share an XCD: keeps tile t on XCD t % 8
+  return cap < 8 ? 8 : cap;
+}
 // experiment knob: extra dynamic LDS per workgroup, i.e. fewer resident GEMM workgroups per CU
 static int g_gemm_lds_pad = 0;
 extern "C" int ser_debug_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes; return 0; }
@@ -554,10 +574,12 @@ static int launch_kernel(const SerGemmArgs* small, const SerGemmArgs& big, hipSt
   if (small) {
     const int tiles0 = ceil_div(small->M, BM) * ceil_div(small->N, BN), total0 = tiles0 * small->nb1 * small->nb2;
     SER_TRY(ps.begin(gemm_flops(*small) + gemm_flops(big), st));
-    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, NS, WR, WC>), dim3((total0 + total1) * ks), dim3(Cfg::NT), g_gemm_lds_pad, st,
-                       *small, big, total0 * ks, tiles0, tiles1);
+    const int all = (total0 + total1) * ks, rc = resident_cap(Cfg::WG_PER_CU);
+    hipLaunchKernelGGL((gemm_bf16_pair_kernel<BM, BN, MODE, NS, WR, WC>), dim3(rc > 0 && rc < all ? rc : all), dim3(Cfg::NT), g_gemm_lds_pad, st,
+                       *small, big, total0 * ks, tiles0, tiles1, all);
   } else {
-    const int cap = g_gemm_persist_cap > 0 ? g_gemm_persist_cap : total1 * ks;
+    const int rc = resident_cap(Cfg::WG_PER_CU);
+    const int cap = g_gemm_persist_cap > 0 ? g_gemm_persist_cap : (rc > 0 ? rc : total1 * ks);
     SER_TRY(ps.begin(gemm_flops(big), st));
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN, MODE, NS, WR, WC>), dim3(total1 * ks < cap ? total1 * ks : cap), dim3(Cfg::NT),
                        g_gemm_lds_pad, st, big, tiles1, total1);

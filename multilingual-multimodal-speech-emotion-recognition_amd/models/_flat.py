@@ -49,15 +49,36 @@ class FlatParams:
             base = self.flat.data_ptr()
             ok = all(p.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
         if not ok:
+            # Stream safety.  Re-pointing `p.data` drops the last reference to the parameter's old storage, and the
+            # caching allocator hands a freed block back to its ALLOCATION stream at once.  When this runs on another
+            # stream (the text-side modules of SERSystem flatten lazily on its side stream) the copies below are still
+            # queued there while the main stream's next allocation — the sibling module's flat buffer has exactly the
+            # size of the merged freed blocks — may reuse and overwrite the block: the parameters then silently become
+            # zeros or the sibling's values (the rare first-loss mismatch of round 2's two-rank rehearsal, DESIGN.md
+            # section 6).  `record_stream` makes the allocator wait for this stream before reusing the old blocks, and
+            # the old flat buffers of a re-flatten are retired the same way.
+            cuda = dev.type == "cuda"
+            cur = torch.cuda.current_stream(dev) if cuda else None
             flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
             for v, p in zip(self._views(flat), self.params):
-                v.copy_(p.data)
+                old = p.data
+                v.copy_(old)
+                if cuda and old.is_cuda:
+                    old.record_stream(cur)
                 p.data = v
+                del old
+            for old in (self.flat, self.gflat):
+                if cuda and old is not None and old.is_cuda:
+                    old.record_stream(cur)
             self.flat = flat
             self.gflat = torch.zeros(self.total, dtype=torch.float32, device=dev)
             self.gviews = self._views(self.gflat)
             for p in self.params:
                 p.grad = None
+            # consumers on OTHER streams (the optimizer, a captured graph) must not run ahead of the copies above: a
+            # (re)flatten is a rare set-up event, so outside graph capture simply drain the device once
+            if cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize(dev)
         return self
 
     def gview(self, p):

@@ -113,7 +113,19 @@ class AudioEncoder(nn.Module):
             self.combined_fusion = nn.Sequential(nn.Linear(hid + 20, hid), nn.ReLU(), nn.Dropout(0.1))
         self.precision = precision
         self._engine = None
-        self._gate_flat = None
+        # flat parameter / gradient buckets of the trainable pieces, created with the module (not on first use: a bucket
+        # that appears in the middle of a forward is flattened on whatever stream happens to be current, and the
+        # data-parallel reducer / optimizer would not know about it before that)
+        from ._flat import FlatParams
+        self._adapter_flat = FlatParams(list(self.adapter.parameters()))
+        mods = []
+        if use_quality_gates:
+            mods += [self.quality_gates.quality_projection, self.quality_fusion]
+        if use_audio_conditioning:
+            mods += [self.audio_conditioning.conditioning_projection, self.conditioning_fusion]
+        if use_quality_gates and use_audio_conditioning:
+            mods += [self.combined_fusion]
+        self._gate_flat = FlatParams([p for m_ in mods for p in m_.parameters()]) if mods else None
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_engine", None))
 
     def _apply(self, fn, *a, **k):
@@ -169,16 +181,6 @@ class AudioEncoder(nn.Module):
 
     def fuse_gate_features(self, seq, quality_raw=None, conditioning_raw=None):
         """seq [B,S,H] + raw quality [B,8] / conditioning [B,12] features -> fused sequence (ref :115-132)."""
-        from ._flat import FlatParams
-        if self._gate_flat is None:
-            mods = []
-            if self.use_quality_gates:
-                mods += [self.quality_gates.quality_projection, self.quality_fusion]
-            if self.use_audio_conditioning:
-                mods += [self.audio_conditioning.conditioning_projection, self.conditioning_fusion]
-            if self.use_quality_gates and self.use_audio_conditioning:
-                mods += [self.combined_fusion]
-            self._gate_flat = FlatParams([p for m_ in mods for p in m_.parameters()])
         self._gate_flat.ensure()
         return _GateFusionFn.apply(self, seq, quality_raw, conditioning_raw, *self._gate_flat.params)
 

@@ -79,22 +79,16 @@ class _CrossFn(torch.autograd.Function):
         a2, t2 = a.reshape(B * Sa, Da).contiguous(), t.reshape(B * St, Dt).contiguous()
         am = a_mask.to(torch.float32).contiguous() if a_mask is not None else None
         tm = t_mask.to(torch.float32).contiguous() if t_mask is not None else None
-        cur = torch.cuda.current_stream()
-        side = _side_stream()
-        side.wait_stream(cur)
-        ya, sa = _dir_fwd(a2, t2, tm, B, Sa, St, m.q_a.weight, m.q_a.bias, m.k_t.weight, m.k_t.bias, m.v_t.weight,
-                          m.v_t.bias, m.attn_a.in_proj_weight, m.attn_a.in_proj_bias, m.attn_a.out_proj.weight,
-                          m.attn_a.out_proj.bias, m.out_a.weight, m.out_a.bias, m.norm_a.weight, m.norm_a.bias, m.num_heads,
-                          m.dropout.p, m._drop_sites[0], m.attn_a.dropout, m._drop_sites[2])
-        with torch.cuda.stream(side):     # T <- A is independent of A <- T
+        with O.fork(_side_stream()) as f:     # T <- A is independent of A <- T
             yt, st = _dir_fwd(t2, a2, am, B, St, Sa, m.q_t.weight, m.q_t.bias, m.k_a.weight, m.k_a.bias, m.v_a.weight,
                               m.v_a.bias, m.attn_t.in_proj_weight, m.attn_t.in_proj_bias, m.attn_t.out_proj.weight,
                               m.attn_t.out_proj.bias, m.out_t.weight, m.out_t.bias, m.norm_t.weight, m.norm_t.bias,
                               m.num_heads, m.dropout.p, m._drop_sites[1], m.attn_t.dropout, m._drop_sites[3])
-        cur.wait_stream(side)
-        for tns in (a2, t2):
-            tns.record_stream(side)
-        yt.record_stream(cur)
+        ya, sa = _dir_fwd(a2, t2, tm, B, Sa, St, m.q_a.weight, m.q_a.bias, m.k_t.weight, m.k_t.bias, m.v_t.weight,
+                          m.v_t.bias, m.attn_a.in_proj_weight, m.attn_a.in_proj_bias, m.attn_a.out_proj.weight,
+                          m.attn_a.out_proj.bias, m.out_a.weight, m.out_a.bias, m.norm_a.weight, m.norm_a.bias, m.num_heads,
+                          m.dropout.p, m._drop_sites[0], m.attn_a.dropout, m._drop_sites[2])
+        f.join(produced=[yt], consumed=[a2, t2, am])
         ctx.m, ctx.dims = m, (B, Sa, St, Da, Dt)
         ctx.sa, ctx.st, ctx.a2, ctx.t2 = sa, st, a2, t2
         return ya.view(B, Sa, Da), yt.view(B, St, Dt)
@@ -114,17 +108,12 @@ class _CrossFn(torch.autograd.Function):
         da2 = torch.empty(B * Sa, Da, dtype=torch.float32, device=dev)      # contributions of the other direction
         dt2 = torch.empty(B * St, Dt, dtype=torch.float32, device=dev)
         dya2, dyt2 = dya.reshape(B * Sa, Da).contiguous(), dyt.reshape(B * St, Dt).contiguous()
-        cur = torch.cuda.current_stream()
-        side = _side_stream()
-        side.wait_stream(cur)
-        _dir_bwd(dya2, ctx.sa, ctx.a2, ctx.t2, B, Sa, St, P(m.q_a), P(m.k_t), P(m.v_t),
-                 PI(m.attn_a), P(m.attn_a.out_proj), P(m.out_a), P(m.norm_a), g, acc, m.num_heads, da, dt2)
-        with torch.cuda.stream(side):     # the two directions touch disjoint parameters and disjoint gradient buffers
+        with O.fork(_side_stream()) as f:     # the two directions touch disjoint parameters and disjoint gradient buffers
             _dir_bwd(dyt2, ctx.st, ctx.t2, ctx.a2, B, St, Sa, P(m.q_t), P(m.k_a), P(m.v_a),
                      PI(m.attn_t), P(m.attn_t.out_proj), P(m.out_t), P(m.norm_t), g, acc, m.num_heads, dt, da2)
-        cur.wait_stream(side)
-        for tns in (dyt2, dt, da2):
-            tns.record_stream(side)
+        _dir_bwd(dya2, ctx.sa, ctx.a2, ctx.t2, B, Sa, St, P(m.q_a), P(m.k_t), P(m.v_t),
+                 PI(m.attn_a), P(m.attn_a.out_proj), P(m.out_a), P(m.norm_a), g, acc, m.num_heads, da, dt2)
+        f.join(consumed=[dyt2, dt, da2])
         O.axpby(da2, da, 1.0, 1.0)
         O.axpby(dt2, dt, 1.0, 1.0)
         fp.publish()

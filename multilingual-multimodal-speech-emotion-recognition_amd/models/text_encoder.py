@@ -44,6 +44,8 @@ class TextEncoder(nn.Module):
         self._asr_model_name = asr_model_name
         self.precision = precision
         self._engine = None
+        from ._flat import FlatParams
+        self._adapter_flat = FlatParams(list(self.adapter.parameters()))     # with the module, not on first use (see AudioEncoder)
         self._register_load_state_dict_pre_hook(lambda *a, **k: setattr(self, "_engine", None))
 
     def _apply(self, fn, *a, **k):

@@ -6,6 +6,7 @@ step (:145-177, :181-201), plus the data-parallel gradient reduction the referen
 (graph replay removes the per-kernel host launch cost of the ~2k small head kernels); the gradient
 all-reduce runs between them.
 """
+import contextlib
 import math
 
 import torch
@@ -121,6 +122,7 @@ class SERSystem(nn.Module):
         """Frozen encoders (one paired call) + the two trainable adapters (independent: the text one on a second
         stream)."""
         from .models.adapter import adapter_apply
+        self.prepare()
         noisy = self.training and (getattr(self.audio_encoder, "encoder_train_noise", False) or getattr(self.text_encoder, "encoder_train_noise", False))
         if noisy or not (self.audio_encoder.freeze_base and self.text_encoder.freeze_base):
             # BASELINE config 3 (reference freeze_base=False): the fine-tuning form of the encoders, with gradients; also the
@@ -130,19 +132,17 @@ class SERSystem(nn.Module):
             a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
             return a_seq, a_mask, t_seq, t_mask
         a_enc, t_enc = self.encode_frozen(wave, ids.to(wave.device), attn_mask.to(wave.device))
-        cur = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        side = self._side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        with _ops.fork(self._side_stream()) as f:
             t_seq = adapter_apply(self.text_encoder, t_enc)
-        t_enc.record_stream(side)
         a_seq = adapter_apply(self.audio_encoder, a_enc)
         a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
-        cur.wait_stream(side)
-        t_seq.record_stream(cur)
+        f.join(produced=[t_seq], consumed=[t_enc])
         return a_seq, a_mask, t_seq, attn_mask.to(device=a_seq.device, dtype=torch.float32)
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     @torch.no_grad()
     def encode_frozen(self, wave, ids, attn_mask, slot=0):
@@ -172,18 +172,13 @@ class SERSystem(nn.Module):
         so that the caller can run the classifier's backward first (loss.backward(): its gradient bucket is then
         complete and can travel over xGMI) and the rest afterwards (fused.backward(leaf.grad))."""
         from .models.adapter import adapter_apply
+        self.prepare()
         self._set_precision()
-        cur = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        side = self._side
         with self._dropout_scope():
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            with _ops.fork(self._side_stream()) as f:
                 t_seq = adapter_apply(self.text_encoder, t_enc)
             a_seq = adapter_apply(self.audio_encoder, a_enc)
-            cur.wait_stream(side)
-            t_seq.record_stream(cur)
+            f.join(produced=[t_seq], consumed=[t_enc])
             a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
             fused = self.head(a_seq, a_mask, t_seq, attn_mask.to(torch.float32))
             leaf = fused.detach().requires_grad_() if split else fused
@@ -194,20 +189,14 @@ class SERSystem(nn.Module):
         return total, logits
 
     def head(self, a_seq, a_mask, t_seq, t_mask):
+        self.prepare()
         a_enh, t_enh = self.cross(a_seq, t_seq, a_mask, t_mask)
         # the two poolings are independent: text pooling (forward, and therefore its backward, which autograd runs
         # on the forward's stream) goes to the side stream
-        cur = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        side = self._side
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
+        with _ops.fork(self._side_stream()) as f:
             t_vec = self.pool_t(t_enh, t_mask)
-        t_enh.record_stream(side)
         a_vec = self.pool_a(a_enh, a_mask)
-        cur.wait_stream(side)
-        t_vec.record_stream(cur)
+        f.join(produced=[t_vec], consumed=[t_enh, t_mask])
         return self.fusion(a_vec, t_vec)
 
     def forward(self, wave, ids, attn_mask, use_openmax=True):
@@ -235,10 +224,22 @@ class SERSystem(nn.Module):
         out = []
         for m in (self.classifier, self.fusion, self.pool_a, self.pool_t, self.cross):
             out.append(m._flat)
+        gate = getattr(self.audio_encoder, "_gate_flat", None)      # quality / conditioning projections + their fusion Linear
+        if gate is not None:
+            out.append(gate)
         for m in (self.audio_encoder, self.text_encoder):
             if hasattr(m, "_adapter_flat"):
                 out.append(m._adapter_flat)
         return out
+
+    def prepare(self):
+        """Flatten every trainable bucket NOW, on the current stream, before the forward forks onto side streams.
+        A bucket that is first flattened in the middle of a forward is built on whatever stream is current there (the
+        text adapter and the text pooling run on the side stream), which is how a freed parameter block came to be reused
+        by the main stream under a still-queued copy (models/_flat.py).  Cheap when nothing moved
+        (pointer comparisons); called at the top of every forward entry."""
+        for b in self.buckets():
+            b.ensure()
 
 
 class GradReducer:
@@ -264,7 +265,8 @@ class GradReducer:
         self.cuda = torch.cuda.is_available() and next(system.parameters()).is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.pending = []
-        self._done = set()
+        self._seq, self._next, self._ready = None, 0, set()
+        self.hold = False
         # issuing a collective while a compute graph replays is the point of the overlap; it is only done on RCCL
         # (gloo stages device tensors through the host and serialises against the replay) unless forced by env
         import os
@@ -274,51 +276,90 @@ class GradReducer:
         # SUM over ranks; the 1/world scale is applied by the library's own axpby kernel in finish()
         return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def _hook(self, bucket):
-        if id(bucket) in self._done:
-            return
-        self._done.add(id(bucket))
+    def _issue(self, t):
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self.pending.append((self._reduce(bucket.gflat), bucket.gflat))
+                self.pending.append((self._reduce(t), t))
         else:
-            self.pending.append((self._reduce(bucket.gflat), bucket.gflat))
+            self.pending.append((self._reduce(t), t))
+
+    # The collectives of one step are issued in ONE fixed sequence on every rank, whatever path a rank's step takes
+    # (eager with per-bucket hooks on a ragged batch, a captured graph on an equal-length one, the two-piece graph):
+    # the buckets in `system.buckets()` order, then the loose parameters, then the fine-tuning buffers.  A hook only
+    # marks its bucket ready; a bucket is issued once every bucket before it has been.  (Issuing in hook order would let
+    # two ranks pair different buckets of equal size - pool_a with pool_t - in one all-reduce.)
+    def _advance(self, upto=None):
+        seq = self._seq
+        while self._next < len(seq) and (upto is None or self._next < upto) and (upto is not None or id(seq[self._next]) in self._ready):
+            b = seq[self._next]
+            self._next += 1
+            if b.gflat is not None:
+                self._issue(b.gflat)
+
+    def _hook(self, bucket):
+        # never from inside a graph capture or its eager warm-up (`hold`): a collective issued there would reduce
+        # gradients the captured replay is about to overwrite
+        if self.hold or (self.cuda and torch.cuda.is_current_stream_capturing()):
+            return
+        self._ready.add(id(bucket))
+        self._advance()
 
     def start(self, buckets, loose=()):
-        """Issue the all-reduce of the given (already complete) buckets now, without waiting for them."""
+        """Issue the all-reduce of the given (already complete) buckets now - as far as the fixed sequence allows -
+        without waiting for them.  (`loose` parameters always travel in finish(), after the buckets.)"""
+        if self._seq is None:
+            self._begin()
         for b in buckets:
-            if b.gflat is not None:
-                self._hook(b)
-        for p in loose:
-            if p.grad is not None and id(p) not in self._done:
-                self._done.add(id(p))
-                if self.cuda:
-                    self.stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self.stream):
-                        self.pending.append((self._reduce(p.grad), p.grad))
-                else:
-                    self.pending.append((self._reduce(p.grad), p.grad))
+            self._ready.add(id(b))
+        self._advance()
+
+    def _begin(self):
+        self._seq = list(self.system.buckets())
+        self._next = 0
+        self._ready = set()
 
     def arm(self):
-        self._done.clear()
+        """Eager stepping only: fire each bucket's all-reduce from its module's backward.  The hooks live for ONE step —
+        finish() removes them — so a later graph capture / replay on the same modules never runs them."""
+        self._begin()
         if self.overlap:
             for b in self.system.buckets():
                 b.grad_ready_hook = self._hook
 
+    def disarm(self):
+        for b in self.system.buckets():
+            b.grad_ready_hook = None
+
+    def quiet(self):
+        """Context for graph capture and its eager warm-up passes: hooks removed, nothing is reduced, nothing marked done."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            prev, self.hold = self.hold, True
+            self.disarm()
+            try:
+                yield
+            finally:
+                self.hold = prev
+                self._seq = None
+                self.pending.clear()
+        return scope()
+
     def finish(self):
-        for b in self.system.buckets():       # anything the hooks did not catch (overlap off, or first step)
-            if b.gflat is not None:
-                self._hook(b)
+        if self._seq is None:
+            self._begin()
+        self._advance(upto=len(self._seq))    # every bucket the hooks / start() have not issued yet, in sequence
         for p in self.loose:
-            if p.grad is not None and id(p) not in self._done:
-                self.pending.append((self._reduce(p.grad), p.grad))
+            if p.grad is not None:
+                self._issue(p.grad)
         back = []
         for group in self.coalesced:
             live = [p for p in group if p.grad is not None]
             if live:
                 flat = torch.cat([p.grad.reshape(-1) for p in live])
-                self.pending.append((self._reduce(flat), flat))
+                self._issue(flat)
                 back.append((flat, live))
         inv = 1.0 / self.world
         if self.cuda:
@@ -339,7 +380,8 @@ class GradReducer:
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
         self.pending.clear()
-        self._done.clear()
+        self._seq = None
+        self.disarm()
 
 
 class TrainStepper:
@@ -439,6 +481,11 @@ class TrainStepper:
         return self.loss
 
     def _capture(self, wave, ids, mask, labels):
+        # a reducer armed by an earlier eager step (ragged batch) must not fire from the warm-up passes or the capture
+        with (self.reducer.quiet() if self.reducer else contextlib.nullcontext()):
+            self._capture_impl(wave, ids, mask, labels)
+
+    def _capture_impl(self, wave, ids, mask, labels):
         dev = wave.device
         self.static = [wave.clone(), ids.clone(), mask.clone(), labels.clone()]
         side = torch.cuda.Stream()
@@ -490,74 +537,96 @@ class TrainStepper:
 
 
 class PipelinedStepper:
-    """Training steps with the frozen-encoder forward of batch t+1 overlapped with the trainable part of batch t.
+    """Training steps with the frozen-encoder forward issued ahead of, and beside, the trainable part.
 
-    With `freeze_base=True` (the reference default, BASELINE config 2) the encoder outputs of a batch do not depend
-    on any parameter the optimizer touches, so computing them one step early changes nothing numerically
-    (tests/test_gpu_system.py checks bit-identity with sequential stepping).  What it buys: the head is ~600 small,
-    latency-bound launches that occupy a handful of CUs each, while the encoder GEMMs fill the chip; on two streams
-    they run side by side instead of back to back.  Every call still executes exactly one encoder forward and one
-    head forward/backward/AdamW update — nothing is cached or skipped, the encoder work is merely issued earlier.
+    With `freeze_base=True` (the reference default, BASELINE config 2) the encoder outputs of a batch do not depend on
+    any parameter the optimizer touches, so computing them early changes nothing numerically
+    (tests/test_gpu_system.py checks bit-identity with sequential stepping).  Two things are bought with that:
 
-    `feed(batch)` must be called once before the first `step`; `step(next_batch)` trains on the batch fed
-    previously and starts the encoders on `next_batch`.
+    * overlap - the head is ~150 small, latency-bound launches that occupy a handful of CUs each, while the encoder
+      GEMMs fill the chip; on two streams they run side by side instead of back to back;
+    * GEMM shape - ONE encoder pass covers `group` consecutive batches (rows of all of them in every launch).  At batch
+      16 a layer GEMM is 3 696 rows = 174-700 tiles on 256 CUs behind a ~4 us launch floor and an ~8 us epilogue (26-38 %
+      MFMA-pipe utilisation); at group 4 it is 14 784 rows and sits with the conv GEMMs at 45-59 %.  Rows are independent
+      (every normalisation of the encoders is per clip, every tile configuration sums k in the same order), so a clip's
+      features are bit-identical whatever it is batched with.
+
+    Every `step` still executes one head forward / backward / AdamW update on a fresh batch, and every batch goes through
+    exactly one encoder pass - nothing is cached or skipped, the encoder work of `group` steps is merely issued as one
+    pass, `group`..`2 group` steps early.  Schedule (two slots, each = input staging + encoder outputs of one group):
+
+        steps of epoch e :   head consumes slot e%2 (encoded during epoch e-1), one batch per step
+                             encoder pass over slot (e+1)%2 runs on the encoder stream (its inputs were fed during e-1)
+                             each step's new batch is staged into slot e%2's INPUT area (the pass that read it is complete)
+        end of epoch e   :   slot e%2's input area is full again -> its encoder pass is issued (after the last head copy)
+
+    `feed(batch)` stages a batch; `prime` = 2 * group feeds are needed before the first `step`; `step(next_batch)` trains on
+    the oldest batch in flight and stages `next_batch`.  `drain()` trains on what is still in flight without new input.
     """
 
-    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_proto=True, split_backward=None, depth=1):
+    def __init__(self, system, optimizer, scheduler=None, reducer=None, use_proto=True, split_backward=None, group=None, depth=None):
         self.sys, self.opt, self.sched, self.reducer, self.use_proto = system, optimizer, scheduler, reducer, use_proto
-        # depth = encoder passes in flight: 1 = the encoders of batch t+1 beside the head of batch t; 2 = those of t+1 and
-        # t+2 beside it (two encoder graphs on two streams with their own workspaces: one chain's small kernels - attention,
-        # LayerNorm, tile tails - run under the other's GEMMs).  Either way every step runs exactly one encoder pass and
-        # one update; `feed` must be called `depth` times before the first `step`.
-        assert depth in (1, 2)
-        self.depth = depth
-        self.enc_streams = [torch.cuda.Stream() for _ in range(depth)]
-        self.g_encs = [None] * depth
+        if group is None:
+            group = depth if depth is not None else 4       # `depth` (round 2: encoder passes in flight) is accepted as an alias
+        assert group >= 1
+        self.group = int(group)
+        self.prime = 2 * self.group
+        self.enc_stream = torch.cuda.Stream()
+        self.g_encs = [None, None]
+        self.enc_done = [torch.cuda.Event(), torch.cuda.Event()]
         self.g_head = self.g_head_b = self.g_opt = None
-        # Data parallel: the head graph is captured in two pieces — A: forward + loss + classifier backward, B: the
-        # backward of fusion / pooling / cross-attention / adapters — and the all-reduce of the classifier bucket (76 MB of
+        # Data parallel: the head graph is captured in two pieces - A: forward + loss + classifier backward, B: the
+        # backward of fusion / pooling / cross-attention / adapters - and the all-reduce of the classifier bucket (76 MB of
         # the 100 MB of gradients) is issued between them, so it travels over xGMI while B runs.  Same arithmetic as the
         # single graph (the two consumers of `fused` add their gradients in the detached leaf).
         self.split = (reducer is not None and reducer.early) if split_backward is None else bool(split_backward)
-        self.refine_plans = True          # in-situ choice between near-tied GEMM tile configurations (refine_gemm_plans)
         self.loss = None
-        self.queue, self.free = [], list(range(depth))       # slots whose encoder pass is in flight (oldest first) / unused
+        self.fill_k, self.fill_n = 0, 0          # slot whose input area is being filled / batches staged in it
+        self.launched = []                       # (slot, batches in it) whose encoder pass has been issued, not yet consumed (oldest first)
+        self.cons_k, self.cons_j, self.cons_n = None, 0, 0       # slot the head is consuming / next batch of it / batches in it
 
-    # single-slot names kept for the measurement scripts
     @property
     def g_enc(self):
         return self.g_encs[0]
 
     @property
-    def enc_stream(self):
-        return self.enc_streams[0]
-
-    @enc_stream.setter
-    def enc_stream(self, st):
-        self.enc_streams[0] = st
-
-    @property
     def pending(self):
-        return len(self.queue) > 0
+        """Batches staged or encoded but not trained on yet."""
+        n = self.fill_n + sum(nv for _, nv in self.launched)
+        if self.cons_k is not None:
+            n += self.cons_n - self.cons_j
+        return n
 
     def _alloc(self, wave, ids, mask, labels):
-        self.in_slots = [[wave.clone(), ids.clone(), mask.clone(), labels.clone()] for _ in range(self.depth)]   # encoder graph inputs
-        self.in_next = self.in_slots[0]
+        G = self.group
+        rep = lambda t: t.repeat(*([G] + [1] * (t.dim() - 1))).contiguous()
+        self.B = wave.shape[0]
+        # per slot: input staging of a whole group (valid contents from the start: the capture warm-up encodes them)
+        self.in_slots = [[rep(wave), rep(ids), rep(mask), rep(labels)] for _ in range(2)]
         self.cur_mask, self.cur_labels = mask.clone(), labels.clone()                # inputs of the head graph
-        self.nxt_labels = labels.clone()
 
     def _capture(self, wave, ids, mask, labels):
+        with (self.reducer.quiet() if self.reducer else contextlib.nullcontext()):
+            self._capture_impl(wave, ids, mask, labels)
+
+    def _capture_impl(self, wave, ids, mask, labels):
         s, dev = self.sys, wave.device
+        s.prepare()                              # flat buckets on the caller's stream, before anything forks
         self._alloc(wave, ids, mask, labels)
+        B = self.B
+        from . import _engines as E
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):            # warm-up outside capture
-            self.enc_slots = []
-            for k in range(self.depth):
-                a, t = s.encode_frozen(self.in_slots[k][0], self.in_slots[k][1], self.in_slots[k][2], slot=k)
-                self.enc_slots.append([a.clone(), t.clone()])
-            self.enc_next = self.enc_slots[0]
-            self.enc_cur = [a.clone(), t.clone()]
+        with torch.cuda.stream(side):            # warm-up outside capture: engines, workspaces, tile plans, optimizer state
+            # every rank captures here with the same shapes: the one point where the tile timing pass can be a collective
+            # (rank 0's plans everywhere); the lazy pass inside the forward is off under data parallelism
+            E.tune_pair(s.audio_encoder.engine(), s.text_encoder.engine(), self.in_slots[0][0].shape[0], self.in_slots[0][0].shape[1],
+                        self.in_slots[0][1].shape[0], self.in_slots[0][1].shape[1], collective=True)
+            a, t = s.encode_frozen(self.in_slots[0][0], self.in_slots[0][1], self.in_slots[0][2])
+            # per slot: encoder outputs of the group + the mask / labels that travel with them
+            self.enc_slots = [[a.clone(), t.clone(), self.in_slots[k][2].clone(), self.in_slots[k][3].clone()] for k in range(2)]
+            self.enc_cur = [a[:B].clone(), t[:B].clone()]
+            del a, t
             for _ in range(2):
                 self.opt.zero_grad(set_to_none=True)
                 self._head_fwd_bwd()
@@ -591,76 +660,43 @@ class PipelinedStepper:
         # `p.grad is None` skips the parameter - its replicas then drift apart (tests/test_gpu_dp.py)
         self._loose_grads = [(p, p.grad) for grp, segs, loose in self.opt._plan for p in loose if p.grad is not None]
         self._pick_encoder_stream()
-        if self.refine_plans:
-            try:
-                self.refine_gemm_plans()
-            except Exception as e:      # noqa: BLE001 - a tuning extra must not take the step down: keep the stand-alone plans
-                import sys
-                sys.stderr.write(f"PipelinedStepper: in-situ plan refinement skipped ({type(e).__name__}: {e})\n")
-                self._capture_encoders()
-                self._reset_grads_after_idle_replays()
 
     def _capture_encoders(self):
+        """One graph per slot: encoders over the slot's staged group -> the slot's output area (+ its mask / labels).
+        Both graphs run on the one encoder stream, never at the same time, and share the engines' workspace."""
         s = self.sys
-        for k in range(self.depth):
+        for k in range(2):
             self.g_encs[k] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_encs[k]):
-                a, t = s.encode_frozen(self.in_slots[k][0], self.in_slots[k][1], self.in_slots[k][2], slot=k)
+                a, t = s.encode_frozen(self.in_slots[k][0], self.in_slots[k][1], self.in_slots[k][2])
                 self.enc_slots[k][0].copy_(a)
                 self.enc_slots[k][1].copy_(t)
+                self.enc_slots[k][2].copy_(self.in_slots[k][2])
+                self.enc_slots[k][3].copy_(self.in_slots[k][3])
 
-    def _replay_all(self, streams=None):
-        """Every encoder graph on its stream beside the head graph(s), joined (idempotent: no optimizer step involved)."""
+    def _replay_all(self, stream=None):
+        """One encoder pass on the encoder stream beside `group` head replays, joined (idempotent: no optimizer step)."""
         cur = torch.cuda.current_stream()
-        streams = streams or self.enc_streams
-        for k, es in enumerate(streams):
-            es.wait_stream(cur)
-            with torch.cuda.stream(es):
-                self.g_encs[k].replay()
-        self.g_head.replay()
-        if self.g_head_b is not None:
-            self.g_head_b.replay()
-        for es in streams:
-            cur.wait_stream(es)
+        es = stream or self.enc_stream
+        es.wait_stream(cur)
+        with torch.cuda.stream(es):
+            self.g_encs[0].replay()
+        for _ in range(self.group):
+            self.g_head.replay()
+            if self.g_head_b is not None:
+                self.g_head_b.replay()
+        cur.wait_stream(es)
 
-    def _overlapped_ms(self, reps=6, streams=None):
+    def _overlapped_ms(self, reps=3, stream=None):
         cur = torch.cuda.current_stream()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(cur)
         for _ in range(reps):
-            self._replay_all(streams)
+            self._replay_all(stream)
         e1.record(cur)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
-
-    def refine_gemm_plans(self, gain=0.988):
-        """The engines pick a tile configuration per GEMM shape from stand-alone timings; where the runner-up is within a
-        few percent, which of the two is faster BESIDE the head graph is a different question (a 32 KB single-buffer tile
-        and an 86 KB three-stage tile tie alone and differ by 3 % of the step here).  For each such shape: switch the plan
-        to each close alternative, re-capture the encoder graph, time the overlapped replay, keep the fastest.  Results are
-        bit-identical either way (same products, same order per accumulator)."""
-        from . import _engines as E
-        self.plan_refinements = []
-        cands = E.close_runner_ups()
-        if not cands:
-            return
-        measure = lambda: min(self._overlapped_ms(8) for _ in range(3))
-        self._overlapped_ms(2)
-        base = measure()
-        for key, best, alts in cands:
-            keep = best
-            for alt in alts:
-                E.set_plan(key, alt)
-                self._capture_encoders()
-                self._overlapped_ms(2)
-                t = measure()
-                if t < base * gain:
-                    self.plan_refinements.append((key[:3], keep, alt, round(base, 3), round(t, 3)))
-                    base, keep = t, alt
-            E.set_plan(key, keep)
-            self._capture_encoders()
-        self._reset_grads_after_idle_replays()
 
     def _head_a(self):
         s = self.sys
@@ -689,18 +725,37 @@ class PipelinedStepper:
         _ops.wgrad_join()
         return loss.detach(), logits.detach()
 
-    def _pick_encoder_stream(self, candidates=6, reps=3):
+    def _pick_encoder_stream(self, candidates=5, reps=2):
         """HIP multiplexes streams onto a few hardware queues; two streams that land on the same queue run their
-        graphs back to back.  Replay the captured graphs beside each other on a few fresh streams and keep, slot by
-        slot, the stream on which they actually overlap (replays are idempotent: no optimizer step is involved)."""
-        for k in range(self.depth):
-            best, best_ms = self.enc_streams[k], float("inf")
-            for es in [self.enc_streams[k]] + [torch.cuda.Stream() for _ in range(candidates - 1)]:
-                ms = self._overlapped_ms(reps, self.enc_streams[:k] + [es])
-                if ms < best_ms * 0.97:
-                    best, best_ms = es, ms
-            self.enc_streams[k] = best
-            self.overlap_ms = best_ms
+        graphs back to back.  Replay the captured graphs beside each other on a few fresh streams and keep the stream on
+        which they actually overlap (replays are idempotent: no optimizer step is involved)."""
+        best, best_ms = self.enc_stream, float("inf")
+        for es in [self.enc_stream] + [torch.cuda.Stream() for _ in range(candidates - 1)]:
+            ms = self._overlapped_ms(reps, es)
+            if ms < best_ms * 0.97:
+                best, best_ms = es, ms
+        self.enc_stream = best
+        self.overlap_ms = best_ms / self.group           # per step
+        self._reset_grads_after_idle_replays()
+
+    def profile_encoder_passes(self, n=3):
+        """`n` encoder passes over slot 0's staged group issued EAGERLY on the encoder stream - the same launches the
+        slot's graph replays, but outside a graph, so that per-launch HIP events (ser_prof_gemm_start / _stop) can
+        bracket them - each beside `group` head-graph replays on the current stream, as in the timed schedule.
+        Idempotent for training state: no optimizer step, gradients reset afterwards."""
+        cur, es = torch.cuda.current_stream(), self.enc_stream
+        torch.cuda.synchronize()
+        for _ in range(n):
+            es.wait_stream(cur)
+            with torch.cuda.stream(es):
+                a, t = self.sys.encode_frozen(self.in_slots[0][0], self.in_slots[0][1], self.in_slots[0][2])
+            for _ in range(self.group):
+                self.g_head.replay()
+                if self.g_head_b is not None:
+                    self.g_head_b.replay()
+            cur.wait_stream(es)
+            a.record_stream(cur), t.record_stream(cur)
+        torch.cuda.synchronize()
         self._reset_grads_after_idle_replays()
 
     def _reset_grads_after_idle_replays(self):
@@ -709,34 +764,51 @@ class PipelinedStepper:
             p.grad = g
 
     def feed(self, wave, ids, mask, labels):
-        """Start the encoders on a batch (a free slot's stream); its head step happens `depth` `step` calls later."""
+        """Stage a batch into the slot being filled (encoder stream); the slot's encoder pass is issued when it is full."""
         if self.g_encs[0] is None:
             self._capture(wave, ids, mask, labels)
-        assert self.free, "every encoder slot is in flight: call step() before feeding again"
-        k = self.free.pop(0)
-        es, cur = self.enc_streams[k], torch.cuda.current_stream()
-        es.wait_stream(cur)                       # previous users of this slot's buffers on the main stream are done
+        k, n, B = self.fill_k, self.fill_n, self.B
+        assert wave.shape[0] == B, "every batch of a pipelined run has the batch size of the first"
+        assert all(k != lk for lk, _ in self.launched), "both slots are in flight: call step() before feeding again"
+        es, cur = self.enc_stream, torch.cuda.current_stream()
+        es.wait_stream(cur)           # the batch's producer, and every head-side copy out of this slot, are on `cur`
         with torch.cuda.stream(es):
             for dst, src in zip(self.in_slots[k], (wave, ids, mask, labels)):
-                dst.copy_(src, non_blocking=True)
-            self.g_encs[k].replay()
-        self.queue.append(k)
+                dst[n * B:(n + 1) * B].copy_(src, non_blocking=True)
+                if src.is_cuda:
+                    src.record_stream(es)
+            n += 1
+            if n == self.group:
+                self.g_encs[k].replay()
+                self.enc_done[k].record(es)
+        if n == self.group:
+            self.launched.append((k, n))
+            self.fill_k, self.fill_n = k ^ 1, 0
+        else:
+            self.fill_n = n
 
-    def step(self, wave, ids, mask, labels):
-        """Head step on the oldest batch in flight, encoders of this batch alongside it."""
-        assert len(self.queue) == self.depth, f"call feed(batch) {self.depth} time(s) before the first step"
-        dev = wave.device
+    def _head_step(self):
+        """Head forward / backward / update on the next encoded batch (no staging)."""
+        dev = self.enc_cur[0].device
         cur = torch.cuda.current_stream()
-        k = self.queue.pop(0)
+        if self.cons_k is None:
+            assert self.launched, "nothing in flight: feed `prime` batches before the first step"
+            (self.cons_k, self.cons_n), self.cons_j = self.launched.pop(0), 0
+            cur.wait_event(self.enc_done[self.cons_k])       # the slot's encoder pass is complete
+        k, j, B = self.cons_k, self.cons_j, self.B
         for p_, g_ in self._loose_grads:          # a caller's zero_grad(set_to_none=True) must not detach them (see _capture)
             p_.grad = g_
-        cur.wait_stream(self.enc_streams[k])      # encoder outputs of the batch to train on are ready
-        self.enc_cur[0].copy_(self.enc_slots[k][0], non_blocking=True)
-        self.enc_cur[1].copy_(self.enc_slots[k][1], non_blocking=True)
-        self.cur_mask.copy_(self.in_slots[k][2], non_blocking=True)
-        self.cur_labels.copy_(self.in_slots[k][3], non_blocking=True)
-        self.free.append(k)
-        self.feed(wave, ids, mask, labels)        # encoders of the NEXT batch: other stream, runs beside the head
+        sl = slice(j * B, (j + 1) * B)
+        self.enc_cur[0].copy_(self.enc_slots[k][0][sl], non_blocking=True)
+        self.enc_cur[1].copy_(self.enc_slots[k][1][sl], non_blocking=True)
+        self.cur_mask.copy_(self.enc_slots[k][2][sl], non_blocking=True)
+        self.cur_labels.copy_(self.enc_slots[k][3][sl], non_blocking=True)
+        self.cons_j += 1
+        if self.cons_j == self.cons_n:
+            self.cons_k = None                    # fully copied out (on `cur`): the slot's next pass waits for `cur` in feed()
+        return dev
+
+    def _head_launch(self, dev):
         self.g_head.replay()
         if self.g_head_b is not None:
             if self.reducer:                      # classifier bucket + prototypes on their way while the rest of backward runs
@@ -749,3 +821,25 @@ class PipelinedStepper:
         if self.sched:
             self.sched.step()
         return self.loss
+
+    def step(self, wave, ids, mask, labels):
+        """Head step on the oldest batch in flight; `wave, ...` is staged for a later encoder pass alongside it."""
+        assert self.pending >= self.prime, f"call feed(batch) {self.prime} times before the first step"
+        dev = self._head_step()
+        self.feed(wave, ids, mask, labels)        # staged (and, every `group` steps, encoded) on the other stream, beside the head
+        return self._head_launch(dev)
+
+    def drain(self):
+        """Train on every batch that is still in flight without staging new ones (end of an epoch); a partly filled slot
+        is encoded as it stands and only its staged batches are trained on.  Yields the loss of each step."""
+        if self.fill_n:
+            k, n = self.fill_k, self.fill_n
+            es, cur = self.enc_stream, torch.cuda.current_stream()
+            es.wait_stream(cur)
+            with torch.cuda.stream(es):           # the rest of the slot still holds older batches: encoded, never consumed
+                self.g_encs[k].replay()
+                self.enc_done[k].record(es)
+            self.launched.append((k, n))
+            self.fill_k, self.fill_n = k ^ 1, 0
+        while self.launched or self.cons_k is not None:
+            yield self._head_launch(self._head_step())

@@ -229,8 +229,16 @@ class HipEngine:
         self.sys.classifier.fit_weibull(feats, gold)
 
     def checkpoint(self, epoch, f1):
+        """The reference's checkpoint dict (ref train.py:249-262).  `optimizer` / `scheduler` are written in the formats of
+        torch.optim.AdamW / LambdaLR, so the reference's own --resume_from (`optimizer.load_state_dict`, ref :100-108) reads
+        a checkpoint written here, and this package reads both (FlatAdamW.load_state_dict, WarmupCosine.load_state_dict)."""
         ck = self.sys.checkpoint_dict()
-        ck.update(optimizer=self.opt.state_dict(), scheduler=self.sched.state_dict(), epoch=epoch, f1=f1)
+        by_name = {(k, n): p for k in self.sys.CKPT_KEYS for n, p in getattr(self.sys, k).named_parameters()}
+        lrs = [g["lr"] for g in self.opt.param_groups]
+        base = [self.opt.base_lr * g["lr_mult"] for g in self.opt.groups]
+        sched = dict(self.sched.state_dict(), base_lrs=base, _last_lr=lrs, _step_count=self.sched.last_epoch + 1,
+                     _get_lr_called_within_step=False, lr_lambdas=[None] * len(base))
+        ck.update(optimizer=self.opt.torch_state_dict(self.sys.torch_param_order(), by_name), scheduler=sched, epoch=epoch, f1=f1)
         return ck
 
 

@@ -82,6 +82,78 @@ def test_bucket_mean_without_hooks():
     _run(False)
 
 
+class _TwinSystem(torch.nn.Module):
+    """Two buckets of EQUAL size (as pool_a / pool_t are): pairing them wrongly in an all-reduce goes unnoticed by gloo."""
+
+    def __init__(self):
+        super().__init__()
+        from ser_amd.models.pooling import AttentiveStatsPooling
+        from ser_amd.models.prototypes import PrototypeMemory
+        torch.manual_seed(0)
+        self.pool_a = AttentiveStatsPooling(16, 8)
+        self.pool_t = AttentiveStatsPooling(16, 8)
+        self.prototypes = PrototypeMemory(4, 8)
+
+    def buckets(self):
+        return [self.pool_a._flat, self.pool_t._flat]
+
+
+def _worker_mixed_paths(rank, world, port, out):
+    """Rank 0 takes the eager path with hooks that fire in the REVERSE of the bucket order (autograd may run pool_t's
+    backward before pool_a's), rank 1 the graph path (everything in finish(), plus an early start() of one bucket): the
+    collectives must still pair bucket with bucket - the reducer issues them in one fixed sequence."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ser_amd.system import GradReducer
+    s = _TwinSystem()
+    for b in s.buckets():
+        b.ensure()
+    red = GradReducer(s, overlap=True)
+    fill = lambda b, bi, step: b.gflat.copy_(torch.arange(b.total, dtype=torch.float32) * (rank + 1) + 100.0 * bi + step)
+    for step in range(3):
+        bs = s.buckets()
+        if rank == 0:
+            red.arm()
+            for bi in (1, 0):                     # reverse order
+                fill(bs[bi], bi, step)
+                bs[bi].publish()
+        else:
+            for bi in (0, 1):
+                fill(bs[bi], bi, step)
+            if step == 1:
+                red.start([bs[1]])               # not first in the sequence: must wait for bucket 0
+            if step == 2:
+                red.start([bs[0]])
+        s.prototypes.prototypes.grad = torch.full((4, 8), float(rank + 1 + step))
+        red.finish()
+        assert all(b.grad_ready_hook is None for b in bs), "hooks must not outlive the step that armed them"
+        mean_scale = sum(r + 1 for r in range(world)) / world
+        for bi, b in enumerate(bs):
+            want = torch.arange(b.total, dtype=torch.float32) * mean_scale + 100.0 * bi + step
+            assert torch.allclose(b.gflat, want), f"rank {rank} step {step}: bucket {bi} was paired with another bucket"
+        assert torch.allclose(s.prototypes.prototypes.grad, torch.full((4, 8), mean_scale + step))
+    # a capture-time warm-up pass (quiet scope) must neither reduce nor leave anything marked
+    with red.quiet():
+        for b in s.buckets():
+            b.publish()
+        assert not red.pending
+    out.put((rank, True))
+    dist.destroy_process_group()
+
+
+def test_ranks_on_different_paths_pair_the_same_buckets():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mixed_paths, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
 # ---- the training loop of train.py under data parallelism, odd number of batches --------------------------------------
 
 class _ToyDataset(torch.utils.data.Dataset):

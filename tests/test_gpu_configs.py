@@ -78,6 +78,78 @@ def test_config4_two_ranks_augment_graph(tmp_path):
     assert res[0][2] == res[1][2], "both replicas evaluate the same model: same validation F1"
 
 
+def _replica_worker(rank, world, port, tmp, extra, q):
+    """train.main on one of two ranks; reports a digest of every trainable parameter after training."""
+    try:
+        import hashlib
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0",
+                          SER_SINGLE_DEVICE="1", SER_DIST_BACKEND="gloo")
+        import ser_amd  # noqa: F401
+        from ser_amd import train as T
+        made = []
+
+        class Engine(T.HipEngine):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                made.append(self)
+        T.HipEngine = Engine
+        T.main(["--synthetic", "22", "--num_labels", "4", "--epochs", "1", "--batch_size", "4", "--save_dir", os.path.join(tmp, f"ck{rank}"),
+                "--audio_model", os.path.join(tmp, "w2v"), "--text_model", os.path.join(tmp, "xlmr"), "--warmup_ratio", "0.0"] + extra)
+        eng = made[0]
+        torch.cuda.synchronize()
+        names = [n for n, p in eng.sys.named_parameters() if p.requires_grad]
+        flat = torch.cat([p.detach().reshape(-1) for _, p in eng.sys.named_parameters() if p.requires_grad]).cpu()
+        assert torch.isfinite(flat).all()
+        per = {n: hashlib.sha1(p.detach().cpu().numpy().tobytes()).hexdigest()[:12] for n, p in eng.sys.named_parameters() if p.requires_grad}
+        q.put((rank, "ok", hashlib.sha1(flat.numpy().tobytes()).hexdigest(), per, len(names)))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "FAIL: " + traceback.format_exc(), None, None, 0))
+        raise
+
+
+def _two_replicas(tmp_path, extra):
+    from tests.test_gpu_cli import _local_models
+    tmp = str(tmp_path)
+    _local_models(tmp)
+    from tokenizers import Tokenizer, models as tkm, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
+    for i in range(150):
+        vocab[f"w{i}"] = len(vocab)
+    tok = Tokenizer(tkm.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.post_processor = processors.TemplateProcessing(single="<s> $A </s>", special_tokens=[("<s>", 0), ("</s>", 2)])
+    PreTrainedTokenizerFast(tokenizer_object=tok, bos_token="<s>", eos_token="</s>", unk_token="<unk>",
+                            pad_token="<pad>").save_pretrained(os.path.join(tmp, "xlmr"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, tmp, extra, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    if res[0][2] != res[1][2]:
+        diff = [n for n in res[0][3] if res[0][3][n] != res[1][3].get(n)]
+        raise AssertionError(f"replicas diverged in {len(diff)} of {res[0][4]} trainable tensors, e.g. {diff[:8]}")
+
+
+def test_two_ranks_graph_steps_with_ragged_and_equal_batches_stay_identical(tmp_path):
+    """a ragged batch takes the eager path and arms the reducer's per-bucket hooks; a later equal-length
+    batch is captured into a graph whose warm-up passes used to fire those hooks (reducing gradients the replay then
+    overwrote, and marking the buckets done).  Mixed 3 s / 4 s corpus with --graph: both replicas must end bit-identical."""
+    _two_replicas(tmp_path, ["--synthetic_seconds", "3,4", "--graph", "--no_bucketing"])
+
+
+def test_two_ranks_with_gates_reduce_the_gate_parameters(tmp_path):
+    """the quality / conditioning projections and their fusion Linear live in the audio encoder's gate
+    bucket; it is part of SERSystem.buckets() now, so its gradients are all-reduced and the replicas' copies stay equal."""
+    _two_replicas(tmp_path, ["--synthetic_seconds", "3", "--use_quality_gates", "--use_audio_conditioning", "--vad_method", "librosa"])
+
+
 def test_config5_large_shapes_match_oracle():
     import __graft_entry__ as ge
     from transformers import Wav2Vec2Config, XLMRobertaConfig

@@ -110,10 +110,12 @@ def test_graph_step_equals_eager_step():
         assert torch.equal(pa, pc), f"{n}: parameters diverged between eager and split-graph stepping"
 
 
-@pytest.mark.parametrize("depth", [1, 2])
-def test_pipelined_stepping_is_bit_identical_to_sequential(depth):
-    """depth = encoder passes in flight beside the head step (1: batch t+1; 2: batches t+1 and t+2, two encoder graphs
-    with their own workspaces): the same losses and parameters as stepping one batch at a time."""
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_pipelined_stepping_is_bit_identical_to_sequential(group):
+    """group = consecutive batches whose frozen-encoder forward runs as ONE pass (all their clips in every GEMM launch),
+    issued one to two groups ahead of the head steps that consume it: the same losses and parameters, bit for bit, as
+    stepping one batch at a time - a clip's features do not depend on what it is batched with.  11 batches: the stream
+    does not end on a group boundary, so `drain()` also trains on a partly filled slot."""
     import __graft_entry__ as ge
     from ser_amd.system import PipelinedStepper, TrainStepper
     dev = torch.device("cuda:0")
@@ -123,19 +125,56 @@ def test_pipelined_stepping_is_bit_identical_to_sequential(depth):
     sys_a.train(); sys_b.train()
     oa, ob = sys_a.make_optimizer(lr=1e-3), sys_b.make_optimizer(lr=1e-3)
     seq = TrainStepper(sys_a, oa, use_graph=False)
-    pipe = PipelinedStepper(sys_b, ob, depth=depth)
-    batches = [[t.to(dev) for t in _batch(200 + i)] for i in range(5)]
+    pipe = PipelinedStepper(sys_b, ob, group=group)
+    n = 11
+    batches = [[t.to(dev) for t in _batch(200 + i)] for i in range(n)]
     seq_losses = [seq.step(*b).item() for b in batches]
-    for j in range(depth):
+    assert pipe.prime == 2 * group
+    for j in range(pipe.prime):
         pipe.feed(*batches[j])
-    pipe_losses = []
-    for i in range(5):
-        nxt = batches[(i + depth) % 5]
-        pipe_losses.append(pipe.step(*nxt).item())
+    pipe_losses = [pipe.step(*batches[i]).item() for i in range(pipe.prime, n)]
+    pipe_losses += [l.item() for l in pipe.drain()]
     torch.cuda.synchronize()
+    assert pipe.pending == 0
     assert seq_losses == pipe_losses, (seq_losses, pipe_losses)
-    for (n, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
-        assert torch.equal(pa, pb), f"{n}: pipelined stepping diverged from sequential stepping"
+    for (nm, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
+        assert torch.equal(pa, pb), f"{nm}: pipelined stepping diverged from sequential stepping"
+
+
+def test_first_forward_on_busy_streams_keeps_every_parameter():
+    """Regression for round 2's rare first-loss mismatch.  The trainable buckets used to be flattened lazily inside the first
+    forward; the text-side ones (text adapter, text pooling) on SERSystem's side stream.  Re-pointing `p.data` frees the old
+    parameter block to its allocation stream at once, the main stream's next bucket (same size = exact fit for the freed,
+    merged block) reused it, and with the device lagging behind the host - here forced by a long spin on the main stream -
+    the side stream's queued copy then read the sibling's zero fill or weights.  Every parameter must survive bit for bit."""
+    import __graft_entry__ as ge
+    dev = torch.device("cuda:0")
+    sysm, _, _ = ge._small_system(dev)
+    sysm.train()
+    want = {n: p.detach().clone() for n, p in sysm.named_parameters()}
+    batch = [t.to(dev) for t in _batch(77)]
+    torch.cuda.synchronize()
+    if hasattr(torch.cuda, "_sleep"):
+        torch.cuda._sleep(400_000_000)        # ~0.2 s on the main stream: everything below queues up behind it
+    loss, _ = sysm.loss(*batch)
+    torch.cuda.synchronize()
+    bad = [n for n, p in sysm.named_parameters() if not torch.equal(p.detach(), want[n])]
+    assert not bad, f"parameters changed by the first forward: {bad[:6]}"
+    # and the pieces flattened by hand on a side stream, as the lazy path did
+    from ser_amd.models.pooling import AttentiveStatsPooling
+    pa, pt = AttentiveStatsPooling(128).to(dev), AttentiveStatsPooling(128).to(dev)
+    ref = {n: p.detach().clone() for n, p in pt.named_parameters()}
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    if hasattr(torch.cuda, "_sleep"):
+        torch.cuda._sleep(400_000_000)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pt._flat.ensure()
+    pa._flat.ensure()
+    torch.cuda.synchronize()
+    for n, p in pt.named_parameters():
+        assert torch.equal(p.detach(), ref[n]), f"pool_t.{n} corrupted by a bucket flattened on another stream"
 
 
 def test_variable_length_clips_pad_like_reference():
