@@ -44,13 +44,15 @@ def hf_configs(stress=False, vocab=250002):
     return wc, xc
 
 
-def build_system(precision, device, num_labels=4, stress=False, vocab=250002, unfreeze=False):
+def build_system(precision, device, num_labels=4, stress=False, vocab=250002, unfreeze=False, front_end=False):
     import ser_amd  # noqa: F401
     from ser_amd.models import AudioEncoder, TextEncoder
     from ser_amd.system import SERSystem
     wc, xc = hf_configs(stress, vocab)
     torch.manual_seed(0)            # identical random-init replicas on every rank
-    ae = AudioEncoder(hf_config=wc, use_quality_gates=False, use_audio_conditioning=False, precision=precision, freeze_base=not unfreeze)
+    # front_end: the reference's default AudioEncoder() - quality gates + audio conditioning before Wav2Vec2 (ref audio_encoder.py:
+    # 25-52,65-132; vad_method "webrtc" is its default: the energy VAD is substituted with the reference's own warning)
+    ae = AudioEncoder(hf_config=wc, use_quality_gates=front_end, use_audio_conditioning=front_end, precision=precision, freeze_base=not unfreeze)
     te = TextEncoder(hf_config=xc, precision=precision, freeze_base=not unfreeze)
     sysm = SERSystem(ae, te, num_labels=num_labels)
     return sysm.to(device), wc, xc
@@ -131,6 +133,42 @@ def cpu_baseline_and_parity(sample, sysm, wc, xc, args):
     return base, err, same, spread
 
 
+def inference_leg(sysm, batches, steps=12):
+    """Forward-only throughput of the same path (ref src/eval.py:160-206: encoders, head, OpenMax logits, softmax / arg-max /
+    energy) on ONE hipGraph over all the resident clips at once (4 x batch clips: the encoder GEMMs see the same rows as a
+    grouped training pass).  Extra key of the bench line; never part of `value`."""
+    from ser_amd import _ops as O
+    was_training = sysm.training
+    sysm.eval()
+    wave, ids, mask = (torch.cat([b[i] for b in batches]).clone() for i in range(3))
+    n = wave.shape[0]
+
+    def fwd():
+        return O.eval_consumers(sysm(wave, ids, mask, use_openmax=True), 1.0)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fwd()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            probs, pred, energy = fwd()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    sysm.train(was_training)
+    ok = bool(torch.isfinite(probs).all())
+    return dict(clips_per_pass=n, ms_per_pass=round(dt / steps * 1e3, 3), utt_per_s=round(n * steps / dt, 1), finite=ok,
+                what="forward only: encoders + head + OpenMax + softmax / arg-max / energy, one hipGraph, inputs resident")
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) through torch.distributed.run as a
     CHILD process — before this process has touched the GPU, and never by exec — and exit with its code."""
@@ -193,11 +231,15 @@ def main():
                     help="consecutive batches whose frozen-encoder forward is issued as ONE pass (rows of all of them in every GEMM launch) "
                          "beside the head steps of the previous group; every batch still gets exactly one encoder pass and one update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the forward-only throughput leg (extra key `inference`)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--cpu-warmup", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds; the timed CPU steps stop early (>= 3 kept) beyond it")
     ap.add_argument("--stress", action="store_true", help="BASELINE config 5 encoder sizes (1024-d, 24 layers)")
+    ap.add_argument("--front-end", action="store_true",
+                    help="run the reference's default AudioEncoder() front end (quality gates + audio conditioning, ~20 device launches per "
+                         "encoder pass, captured in the encoder graph) and fuse its features; the CPU parity / baseline legs are skipped")
     ap.add_argument("--unfreeze", action="store_true",
                     help="BASELINE config 3: full fine-tune (encoders unfrozen, reference freeze_base=False); use with --batch 8")
     args = ap.parse_args()
@@ -243,7 +285,9 @@ def main():
         L.lib.ser_debug_set_gemm_persist(int(os.environ["SER_GEMM_PERSIST"]))
     if os.environ.get("SER_HEAD_PRIORITY"):       # A/B: step on a stream of this priority (-1 = high) instead of the default stream
         torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ["SER_HEAD_PRIORITY"])))
-    sysm, wc, xc = build_system(args.precision, dev, stress=args.stress, unfreeze=args.unfreeze)
+    sysm, wc, xc = build_system(args.precision, dev, stress=args.stress, unfreeze=args.unfreeze, front_end=args.front_end)
+    if args.front_end:
+        args.no_cpu_baseline = True                # the oracle's timed step has no front end; its kernels are pinned by tests/test_gpu_frontend.py
     sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
     if args.unfreeze:                              # the encoders' own training-mode noise, as the reference's .train() gives it
         for m in (sysm.audio_encoder, sysm.text_encoder):
@@ -351,6 +395,9 @@ def main():
                           "products per multiply, so the matrix pipes run at mfma_pipe_utilisation = products x frac of the dense bf16 "
                           "peak.  Context (profiles/r02_c_gemm_vs_vendor.txt): hipBLASLt's one-product bf16 kernels reach 25-26 % of "
                           "peak on the same M = 3696 layer shapes and 38-58 % on the conv / 4096^3 shapes"))
+    infer = None
+    if rank == 0 and not args.unfreeze and not args.no_inference:
+        infer = inference_leg(sysm, batches)
     if world > 1:
         dist.barrier()
 
@@ -384,6 +431,8 @@ def main():
                                      "encoder pass and one update, bit-identical to sequential stepping") % (args.group, args.group * args.batch))
                                    if pipeline else "sequential",
                        "encoder_group": args.group if pipeline else 1,
+                       "front_end": ("quality gates + audio conditioning of the reference's default AudioEncoder() inside the encoder graph, "
+                                     "features fused in the head" if args.front_end else "off (use_quality_gates=False, use_audio_conditioning=False)"),
                        "stress_sizes": bool(args.stress),
                        "allreduce_overlap": (None if world == 1 else
                                              (("classifier bucket (76 of 100 MB) all-reduced over %s beside the backward of fusion / pooling / "
@@ -397,6 +446,7 @@ def main():
             "parity_on": "initial weights, before the first optimizer step", "oracle_logit_spread_across_clips": spread,
             "whole_step_algorithmic_tflops": None if step_tflops is None else round(step_tflops, 2),
             "loss": round(loss, 5),
+            "inference": infer,
             "gemm_plans": gemm_plans(args, wc, args.group if pipeline else 1),
         }
         print(json.dumps(out))

@@ -471,6 +471,8 @@ int ser_debug_posconv(const float* z, const uint16_t* w_il, const float* bias, f
                       int direct, uint16_t* slab_il, void* stream);
 int ser_debug_barrier_probe(int G, int rounds, int mode, void* flags, void* data, void* errors, void* stream);
 int ser_debug_stack_timeline(void* buf);
+/* out[2 b] = shader cycles, out[2 b + 1] = 100 MHz ticks that block b's dependent-FMA loop of `iters` steps took */
+int ser_debug_clock_probe(void* out, int blocks, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -238,6 +238,11 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False, collective=Fa
         return
     if _world() > 1 and not collective:
         return
+    if os.environ.get("SER_GEMM_FORCE_CFG"):      # experiments: one tile configuration for every shape, no timing pass
+        for rows, N, K in shapes:
+            if N >= 128 and rows > 64:
+                L.lib.ser_gemm_tile_hint_mode(int(rows), int(N), int(K), 1 if three_products else 0, int(os.environ["SER_GEMM_FORCE_CFG"]))
+        return
     pm = 2 if three_products else 1
     fresh = []
     for rows, N, K in shapes:

@@ -628,6 +628,7 @@ static int launch_wide(int cfg, const SerGemmArgs* small, const SerGemmArgs& big
     case SER_GEMM_CFG_256x128: return launch_kernel<256, 128, M_X3I, 2, 4, 2>(small, big, st);
     case SER_GEMM_CFG_128x256_3: return launch_kernel<128, 256, M_X3I, 3, 2, 4>(small, big, st);    // three LDS buffers: two k-tiles in flight
     case SER_GEMM_CFG_256x128_3: return launch_kernel<256, 128, M_X3I, 3, 4, 2>(small, big, st);
+    case SER_GEMM_CFG_256x256_4W: return launch_kernel<256, 256, M_X3I, 2, 2, 2>(small, big, st);   // four waves, 128 x 128 each, 512 registers per lane
     default: break;
   }
   ser_set_error("gemm_bf16: unknown tile configuration %d", cfg);

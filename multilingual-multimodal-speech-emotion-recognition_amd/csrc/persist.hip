@@ -674,6 +674,29 @@ extern "C" int ser_debug_barrier_probe(int G, int rounds, int mode, void* flags,
   return SER_OK;
 }
 
+// Clock probe: one wave spins on dependent VALU work for `iters` iterations and reports the shader clock it ran at
+// (delta s_memtime = shader cycles, delta s_memrealtime = 100 MHz ticks; MI355X_MICROARCH.md, DVFS give-back item 6).
+// Launched beside other work it shows what clock the rest of the chip leaves to a latency-bound kernel.
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int iters) {
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  float x = (float)threadIdx.x;
+  for (int i = 0; i < iters; ++i) x = fmaf(x, 1.0000001f, 1e-7f);
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = c1 - c0;
+    out[2 * blockIdx.x + 1] = r1 - r0;
+  }
+  if (x == 123456.789f) out[0] = 0;
+}
+}  // namespace
+extern "C" int ser_debug_clock_probe(void* out, int blocks, int iters, void* stream) {
+  SER_REQUIRE(out && blocks >= 1 && iters >= 1, "clock probe: bad arguments");
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)out, iters);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 static int stack_check(int L, int M, int D) {
   SER_REQUIRE(L >= 1 && M >= 1 && M <= 16 && D >= 16 && D <= 512 && D % 16 == 0,
               "classifier stack: L=%d M=%d D=%d unsupported (M <= 16, D a multiple of 16 up to 512)", L, M, D);

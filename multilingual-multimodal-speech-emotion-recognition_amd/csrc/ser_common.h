@@ -198,7 +198,7 @@ struct SerGemmArgs {
 };
 // tile configurations: 64..192 = rows of a 256-thread BM x 128 tile; the 512-thread tiles:
 enum { SER_GEMM_CFG_NARROW = 7000 /* + rows: BM x 64 tiles */, SER_GEMM_CFG_SINGLE = 3000 /* + rows: single LDS buffer, three workgroups per CU */, SER_GEMM_CFG_WIDE = 1000, SER_GEMM_CFG_128x256 = 1128, SER_GEMM_CFG_192x256 = 1192, SER_GEMM_CFG_256x256 = 1256, SER_GEMM_CFG_256x128 = 2256,
-       SER_GEMM_CFG_128x256_3 = 5128, SER_GEMM_CFG_256x128_3 = 6256 };
+       SER_GEMM_CFG_128x256_3 = 5128, SER_GEMM_CFG_256x128_3 = 6256, SER_GEMM_CFG_256x256_4W = 8256 };
 int ser_launch_gemm_bf16(const SerGemmArgs& g, hipStream_t st);
 extern "C" int ser_gemm_plan_get(long long rows_total, int N, int K, int three_products, int* cfg, int* ksplit);
 int ser_launch_gemm_bf16_pair(const SerGemmArgs& small, const SerGemmArgs& big, hipStream_t st);

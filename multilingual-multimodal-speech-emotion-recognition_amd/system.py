@@ -118,9 +118,10 @@ class SERSystem(nn.Module):
         ], lr=lr, weight_decay=0.05)
 
     # ---- forward pieces ------------------------------------------------------------------------------------------
-    def encode(self, wave, ids, attn_mask):
+    def encode(self, wave, ids, attn_mask, lid=None):
         """Frozen encoders (one paired call) + the two trainable adapters (independent: the text one on a second
-        stream)."""
+        stream).  With the audio encoder's gate flags on (the reference's default AudioEncoder()), the front end runs first
+        and the projected quality / conditioning features are fused into the audio sequence (ref audio_encoder.py:65-132)."""
         from .models.adapter import adapter_apply
         self.prepare()
         noisy = self.training and (getattr(self.audio_encoder, "encoder_train_noise", False) or getattr(self.text_encoder, "encoder_train_noise", False))
@@ -131,18 +132,71 @@ class SERSystem(nn.Module):
             t_seq, t_mask = self.text_encoder.forward_ids(ids.to(wave.device), attn_mask.to(wave.device))
             a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
             return a_seq, a_mask, t_seq, t_mask
+        q_raw = c_raw = None
+        if self.gates_on():
+            wave, q_raw, c_raw = self.front_end(wave, lid)
         a_enc, t_enc = self.encode_frozen(wave, ids.to(wave.device), attn_mask.to(wave.device))
         with _ops.fork(self._side_stream()) as f:
             t_seq = adapter_apply(self.text_encoder, t_enc)
         a_seq = adapter_apply(self.audio_encoder, a_enc)
-        a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
+        if q_raw is not None or c_raw is not None:
+            a_seq = self.audio_encoder.fuse_gate_features(a_seq, q_raw, c_raw)
+        a_mask = self._ones_mask(a_seq)
         f.join(produced=[t_seq], consumed=[t_enc])
         return a_seq, a_mask, t_seq, attn_mask.to(device=a_seq.device, dtype=torch.float32)
+
+    def _ones_mask(self, seq):
+        """[B, S] of ones (HF returns no attention mask for wav2vec2-base: ref audio_encoder.py:162-163), cached per shape so a
+        step does not launch a fill kernel for it."""
+        key = (seq.shape[0], seq.shape[1], seq.device)
+        m = getattr(self, "_mask_cache", None)
+        if m is None or m[0] != key:
+            self._mask_cache = m = (key, torch.ones(seq.shape[0], seq.shape[1], dtype=torch.float32, device=seq.device))
+        return m[1]
 
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream()
         return self._side
+
+    # ---- the reference's default front end (quality gates + audio conditioning, ref audio_encoder.py:65-132) ----------
+    def gates_on(self):
+        ae = self.audio_encoder
+        return bool(getattr(ae, "use_quality_gates", False) or getattr(ae, "use_audio_conditioning", False))
+
+    def language_features(self, texts, n):
+        """[n, 2] host tensor for `front_end` (ref quality_gates.py:252-301,514-517); texts=None: the no-transcript branch."""
+        from .models.frontend import language_features
+        qg = getattr(self.audio_encoder, "quality_gates", None)
+        return language_features(texts, n, getattr(qg, "language_detector", None), getattr(qg, "enable_language_detection", True))
+
+    @torch.no_grad()
+    def front_end(self, wave, lid=None):
+        """Quality gates -> clips that are not accepted become silence -> audio conditioning, for a whole batch of
+        equal-length clips on the device (ref audio_encoder.py:67-86; ~20 launches, no host decision, capturable):
+        wave [B,T], lid [B,2] (language_features; default = no transcript) -> (wave for the encoder, q_raw [B,8] | None,
+        c_raw [B,12] | None)."""
+        ae = self.audio_encoder
+        q_raw = c_raw = dec = None
+        wave = wave.to(torch.float32)
+        if ae.use_quality_gates:
+            if lid is None:
+                lid = self.language_features(None, wave.shape[0])
+            qg = ae.quality_gates
+            q_raw, _, dec = _ops.quality_gates(wave, lid.to(wave.device, non_blocking=True), qg.pad_mode, qg.sample_rate)
+            if not ae.use_audio_conditioning:
+                wave = wave * (dec == 2).to(wave.dtype)[:, None]                     # ref :74-77
+        if ae.use_audio_conditioning:
+            wave, c_raw, _ = _ops.audio_conditioning(wave, dec, ae.audio_conditioning.sample_rate)   # not accepted -> silence
+        return wave, q_raw, c_raw
+
+    @torch.no_grad()
+    def encode_frozen_gated(self, wave, ids, attn_mask, lid=None, slot=0):
+        """front_end + the frozen encoders -> (a_enc, t_enc, q_raw, c_raw); the raw features are fused into the audio
+        sequence by the trainable gate modules in the head (`loss_from_encoded(gate_features=...)`)."""
+        wave, q_raw, c_raw = self.front_end(wave, lid)
+        a_enc, t_enc = self.encode_frozen(wave, ids, attn_mask, slot)
+        return a_enc, t_enc, q_raw, c_raw
 
     @torch.no_grad()
     def encode_frozen(self, wave, ids, attn_mask, slot=0):
@@ -166,7 +220,7 @@ class SERSystem(nn.Module):
         self._drop_state.add_(1)                                  # one launch; captured with the step, so replays advance it
         return _ops.dropout_scope(self._drop_state)
 
-    def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True, split=False):
+    def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True, split=False, gate_features=None):
         """Everything trainable: adapters -> cross-attention -> pooling -> fusion -> classifier -> loss.
         split=True: the classifier and the loss hang off a detached copy of `fused`; returns (loss, logits, fused, leaf),
         so that the caller can run the classifier's backward first (loss.backward(): its gradient bucket is then
@@ -178,8 +232,10 @@ class SERSystem(nn.Module):
             with _ops.fork(self._side_stream()) as f:
                 t_seq = adapter_apply(self.text_encoder, t_enc)
             a_seq = adapter_apply(self.audio_encoder, a_enc)
+            if gate_features is not None and (gate_features[0] is not None or gate_features[1] is not None):
+                a_seq = self.audio_encoder.fuse_gate_features(a_seq, gate_features[0], gate_features[1])
             f.join(produced=[t_seq], consumed=[t_enc])
-            a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
+            a_mask = self._ones_mask(a_seq)
             fused = self.head(a_seq, a_mask, t_seq, attn_mask.to(torch.float32))
             leaf = fused.detach().requires_grad_() if split else fused
             logits, unc, _ = self.classifier(leaf, use_openmax=False, return_uncertainty=True)
@@ -199,14 +255,14 @@ class SERSystem(nn.Module):
         f.join(produced=[t_vec], consumed=[t_enh, t_mask])
         return self.fusion(a_vec, t_vec)
 
-    def forward(self, wave, ids, attn_mask, use_openmax=True):
-        fused = self.head(*self.encode(wave, ids, attn_mask))
+    def forward(self, wave, ids, attn_mask, use_openmax=True, lid=None):
+        fused = self.head(*self.encode(wave, ids, attn_mask, lid))
         return self.classifier(fused, use_openmax=use_openmax)
 
-    def loss(self, wave, ids, attn_mask, labels, use_proto=True):
+    def loss(self, wave, ids, attn_mask, labels, use_proto=True, lid=None):
         self._set_precision()
         with self._dropout_scope():
-            fused = self.head(*self.encode(wave, ids, attn_mask))
+            fused = self.head(*self.encode(wave, ids, attn_mask, lid))
             logits, unc, anchor = self.classifier(fused, use_openmax=False, return_uncertainty=True)
         total = self.criterion(logits, unc, fused, self.prototypes.prototypes, labels, use_proto=use_proto)
         return total, logits
@@ -319,11 +375,14 @@ class GradReducer:
         self._next = 0
         self._ready = set()
 
-    def arm(self):
+    def arm(self, overlap=None):
         """Eager stepping only: fire each bucket's all-reduce from its module's backward.  The hooks live for ONE step —
-        finish() removes them — so a later graph capture / replay on the same modules never runs them."""
+        finish() removes them — so a later graph capture / replay on the same modules never runs them.
+        overlap=False: no hooks, everything travels in finish() - REQUIRED when a module's backward runs more than once
+        per step (a ragged batch encodes each clip length separately, so the audio adapter publishes its bucket once per
+        length group: the first publish would send a partial gradient)."""
         self._begin()
-        if self.overlap:
+        if self.overlap if overlap is None else overlap:
             for b in self.system.buckets():
                 b.grad_ready_hook = self._hook
 
@@ -408,8 +467,8 @@ class TrainStepper:
         self._graphs = {}
         self.max_graphs = 8
 
-    def _fwd_bwd(self, wave, ids, mask, labels):
-        loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto)
+    def _fwd_bwd(self, wave, ids, mask, labels, lid=None):
+        loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto, lid=lid)
         # eager data parallelism reduces a bucket from its module's backward hook, so gradients cannot be deferred there
         with _ops.defer_wgrads(self.use_graph or self.reducer is None):
             loss.backward()
@@ -417,11 +476,11 @@ class TrainStepper:
         return loss.detach(), logits.detach()
 
     # ---- split form: the classifier + loss hang off a detached copy of `fused`
-    def _fwd_bwd_a(self, wave, ids, mask, labels):
+    def _fwd_bwd_a(self, wave, ids, mask, labels, lid=None):
         s = self.sys
         s._set_precision()
         with s._dropout_scope():              # the same precision mode and training-mode dropout as SERSystem.loss
-            fused = s.head(*s.encode(wave, ids, mask))
+            fused = s.head(*s.encode(wave, ids, mask, lid))
             leaf = fused.detach().requires_grad_()
             logits, unc, _ = s.classifier(leaf, use_openmax=False, return_uncertainty=True)
         loss = s.criterion(logits, unc, leaf, s.prototypes.prototypes, labels, use_proto=self.use_proto)
@@ -437,13 +496,17 @@ class TrainStepper:
         _ops.wgrad_join()
         self._fused = self._dfused = None
 
-    def step(self, wave, ids, mask, labels):
+    def step(self, wave, ids, mask, labels, lid=None):
+        """lid: [B, 2] language features for the quality gates (SERSystem.language_features) when the audio encoder's gate
+        flags are on; default: the no-transcript branch."""
         dev = wave.device
+        if self.sys.gates_on() and lid is None:
+            lid = self.sys.language_features(None, wave.shape[0]).to(dev)
         if not self.use_graph:
             self.opt.zero_grad(set_to_none=True)
             if self.reducer:
                 self.reducer.arm()
-            self.loss, self.logits = self._fwd_bwd(wave, ids, mask, labels)
+            self.loss, self.logits = self._fwd_bwd(wave, ids, mask, labels, lid)
             if self.reducer:
                 self.reducer.finish()
             self.opt.prepare_step(dev)
@@ -454,18 +517,18 @@ class TrainStepper:
                 if len(self._graphs) >= self.max_graphs:      # too many shapes to keep a graph for each: eager step
                     self.use_graph = False
                     try:
-                        return self.step(wave, ids, mask, labels)
+                        return self.step(wave, ids, mask, labels, lid)
                     finally:
                         self.use_graph = True
                 g_opt = self.g_opt
-                self._capture(wave, ids, mask, labels)
+                self._capture(wave, ids, mask, labels, lid)
                 if g_opt is not None:
                     self.g_opt = g_opt                          # the optimizer launch does not depend on the input shape
                 self._graphs[key] = (self.static, self.g_fb, self.g_b, self.loss, self.logits)
             self.static, self.g_fb, self.g_b, self.loss, self.logits = self._graphs[key]
             for p_, g_ in getattr(self, "_loose_grads", ()):      # a caller's zero_grad(set_to_none=True) must not detach them
                 p_.grad = g_
-            for s, t in zip(self.static, (wave, ids, mask, labels)):
+            for s, t in zip(self.static, (wave, ids, mask, labels) + ((lid,) if lid is not None else ())):
                 s.copy_(t, non_blocking=True)
             self.g_fb.replay()
             if self.split:
@@ -480,14 +543,15 @@ class TrainStepper:
             self.sched.step()
         return self.loss
 
-    def _capture(self, wave, ids, mask, labels):
+    def _capture(self, wave, ids, mask, labels, lid=None):
         # a reducer armed by an earlier eager step (ragged batch) must not fire from the warm-up passes or the capture
         with (self.reducer.quiet() if self.reducer else contextlib.nullcontext()):
-            self._capture_impl(wave, ids, mask, labels)
+            self._capture_impl(wave, ids, mask, labels, lid)
 
-    def _capture_impl(self, wave, ids, mask, labels):
+    def _capture_impl(self, wave, ids, mask, labels, lid=None):
         dev = wave.device
-        self.static = [wave.clone(), ids.clone(), mask.clone(), labels.clone()]
+        self.sys.prepare()
+        self.static = [wave.clone(), ids.clone(), mask.clone(), labels.clone()] + ([lid.clone()] if lid is not None else [])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):       # warm-up outside capture: workspaces, flat buckets, optimizer state
@@ -604,6 +668,13 @@ class PipelinedStepper:
         # per slot: input staging of a whole group (valid contents from the start: the capture warm-up encodes them)
         self.in_slots = [[rep(wave), rep(ids), rep(mask), rep(labels)] for _ in range(2)]
         self.cur_mask, self.cur_labels = mask.clone(), labels.clone()                # inputs of the head graph
+        # the reference's default front end (gate flags of the audio encoder on): its 20 launches head the encoder graph; the
+        # per-clip language features are one more staged input, the raw quality / conditioning features two more outputs
+        self.gated = self.sys.gates_on()
+        if self.gated:
+            lid = self.sys.language_features(None, self.B).to(wave.device)
+            for sl in self.in_slots:
+                sl.append(rep(lid))
 
     def _capture(self, wave, ids, mask, labels):
         with (self.reducer.quiet() if self.reducer else contextlib.nullcontext()):
@@ -622,11 +693,12 @@ class PipelinedStepper:
             # (rank 0's plans everywhere); the lazy pass inside the forward is off under data parallelism
             E.tune_pair(s.audio_encoder.engine(), s.text_encoder.engine(), self.in_slots[0][0].shape[0], self.in_slots[0][0].shape[1],
                         self.in_slots[0][1].shape[0], self.in_slots[0][1].shape[1], collective=True)
-            a, t = s.encode_frozen(self.in_slots[0][0], self.in_slots[0][1], self.in_slots[0][2])
-            # per slot: encoder outputs of the group + the mask / labels that travel with them
-            self.enc_slots = [[a.clone(), t.clone(), self.in_slots[k][2].clone(), self.in_slots[k][3].clone()] for k in range(2)]
-            self.enc_cur = [a[:B].clone(), t[:B].clone()]
-            del a, t
+            a, t, *gf = self._encode_slot(0)
+            # per slot: encoder outputs of the group + the mask / labels (+ raw gate features) that travel with them
+            self.enc_slots = [[a.clone(), t.clone(), self.in_slots[k][2].clone(), self.in_slots[k][3].clone()] + [x.clone() for x in gf]
+                              for k in range(2)]
+            self.enc_cur = [a[:B].clone(), t[:B].clone()] + [x[:B].clone() for x in gf]
+            del a, t, gf
             for _ in range(2):
                 self.opt.zero_grad(set_to_none=True)
                 self._head_fwd_bwd()
@@ -661,18 +733,36 @@ class PipelinedStepper:
         self._loose_grads = [(p, p.grad) for grp, segs, loose in self.opt._plan for p in loose if p.grad is not None]
         self._pick_encoder_stream()
 
+    def _encode_slot(self, k):
+        """(front end +) frozen encoders over slot k's staged group -> [a_enc, t_enc (, q_raw, c_raw: the gate features present)]."""
+        sl = self.in_slots[k]
+        if not self.gated:
+            return list(self.sys.encode_frozen(sl[0], sl[1], sl[2]))
+        a, t, q, c = self.sys.encode_frozen_gated(sl[0], sl[1], sl[2], sl[4])
+        self._gate_idx = [i for i, x in enumerate((q, c)) if x is not None]          # which of (quality, conditioning) travel
+        return [a, t] + [x for x in (q, c) if x is not None]
+
+    def _gate_features(self):
+        if not self.gated:
+            return None
+        gf = [None, None]
+        for j, i in enumerate(self._gate_idx):
+            gf[i] = self.enc_cur[2 + j]
+        return tuple(gf)
+
     def _capture_encoders(self):
-        """One graph per slot: encoders over the slot's staged group -> the slot's output area (+ its mask / labels).
-        Both graphs run on the one encoder stream, never at the same time, and share the engines' workspace."""
-        s = self.sys
+        """One graph per slot: (front end +) encoders over the slot's staged group -> the slot's output area (+ its mask /
+        labels).  Both graphs run on the one encoder stream, never at the same time, and share the engines' workspace."""
         for k in range(2):
             self.g_encs[k] = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_encs[k]):
-                a, t = s.encode_frozen(self.in_slots[k][0], self.in_slots[k][1], self.in_slots[k][2])
-                self.enc_slots[k][0].copy_(a)
-                self.enc_slots[k][1].copy_(t)
+                outs = self._encode_slot(k)
+                self.enc_slots[k][0].copy_(outs[0])
+                self.enc_slots[k][1].copy_(outs[1])
                 self.enc_slots[k][2].copy_(self.in_slots[k][2])
                 self.enc_slots[k][3].copy_(self.in_slots[k][3])
+                for j, x in enumerate(outs[2:]):
+                    self.enc_slots[k][4 + j].copy_(x)
 
     def _replay_all(self, stream=None):
         """One encoder pass on the encoder stream beside `group` head replays, joined (idempotent: no optimizer step)."""
@@ -701,7 +791,7 @@ class PipelinedStepper:
     def _head_a(self):
         s = self.sys
         loss, logits, fused, leaf = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels,
-                                                        self.use_proto, split=True)
+                                                        self.use_proto, split=True, gate_features=self._gate_features())
         with _ops.defer_wgrads():
             loss.backward()
         _ops.wgrad_join()
@@ -719,7 +809,8 @@ class PipelinedStepper:
             out = self._head_a()
             self._head_b()
             return out
-        loss, logits = self.sys.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto)
+        loss, logits = self.sys.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto,
+                                                  gate_features=self._gate_features())
         with _ops.defer_wgrads():
             loss.backward()
         _ops.wgrad_join()
@@ -748,13 +839,14 @@ class PipelinedStepper:
         for _ in range(n):
             es.wait_stream(cur)
             with torch.cuda.stream(es):
-                a, t = self.sys.encode_frozen(self.in_slots[0][0], self.in_slots[0][1], self.in_slots[0][2])
+                outs = self._encode_slot(0)
             for _ in range(self.group):
                 self.g_head.replay()
                 if self.g_head_b is not None:
                     self.g_head_b.replay()
             cur.wait_stream(es)
-            a.record_stream(cur), t.record_stream(cur)
+            for x in outs:
+                x.record_stream(cur)
         torch.cuda.synchronize()
         self._reset_grads_after_idle_replays()
 
@@ -763,8 +855,10 @@ class PipelinedStepper:
         for p, g in self._loose_grads:           # keep pointing at the tensors the captured graphs write (see _capture)
             p.grad = g
 
-    def feed(self, wave, ids, mask, labels):
-        """Stage a batch into the slot being filled (encoder stream); the slot's encoder pass is issued when it is full."""
+    def feed(self, wave, ids, mask, labels, lid=None):
+        """Stage a batch into the slot being filled (encoder stream); the slot's encoder pass is issued when it is full.
+        lid: [B, 2] language features of the clips' transcripts for the quality gates (SERSystem.language_features;
+        default: the no-transcript branch) - only read when the audio encoder's gate flags are on."""
         if self.g_encs[0] is None:
             self._capture(wave, ids, mask, labels)
         k, n, B = self.fill_k, self.fill_n, self.B
@@ -773,7 +867,10 @@ class PipelinedStepper:
         es, cur = self.enc_stream, torch.cuda.current_stream()
         es.wait_stream(cur)           # the batch's producer, and every head-side copy out of this slot, are on `cur`
         with torch.cuda.stream(es):
-            for dst, src in zip(self.in_slots[k], (wave, ids, mask, labels)):
+            srcs = [wave, ids, mask, labels]
+            if self.gated:
+                srcs.append(lid if lid is not None else self.sys.language_features(None, B))
+            for dst, src in zip(self.in_slots[k], srcs):
                 dst[n * B:(n + 1) * B].copy_(src, non_blocking=True)
                 if src.is_cuda:
                     src.record_stream(es)
@@ -803,6 +900,8 @@ class PipelinedStepper:
         self.enc_cur[1].copy_(self.enc_slots[k][1][sl], non_blocking=True)
         self.cur_mask.copy_(self.enc_slots[k][2][sl], non_blocking=True)
         self.cur_labels.copy_(self.enc_slots[k][3][sl], non_blocking=True)
+        for j in range(2, len(self.enc_cur)):                     # raw gate features of the batch
+            self.enc_cur[j].copy_(self.enc_slots[k][2 + j][sl], non_blocking=True)
         self.cons_j += 1
         if self.cons_j == self.cons_n:
             self.cons_k = None                    # fully copied out (on `cur`): the slot's next pass waits for `cur` in feed()
@@ -822,11 +921,11 @@ class PipelinedStepper:
             self.sched.step()
         return self.loss
 
-    def step(self, wave, ids, mask, labels):
+    def step(self, wave, ids, mask, labels, lid=None):
         """Head step on the oldest batch in flight; `wave, ...` is staged for a later encoder pass alongside it."""
         assert self.pending >= self.prime, f"call feed(batch) {self.prime} times before the first step"
         dev = self._head_step()
-        self.feed(wave, ids, mask, labels)        # staged (and, every `group` steps, encoded) on the other stream, beside the head
+        self.feed(wave, ids, mask, labels, lid)   # staged (and, every `group` steps, encoded) on the other stream, beside the head
         return self._head_launch(dev)
 
     def drain(self):

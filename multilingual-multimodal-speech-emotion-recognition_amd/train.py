@@ -183,15 +183,16 @@ class HipEngine:
             wave = torch.stack(audio_list).to(dev)
             if self.aug:
                 wave = self.aug.device(wave, noise_seed=(epoch * 1000003 + step) * 64 + self.rank)
-            if not self.gated:
-                return self.stepper.step(wave, ids, mask, labels.to(dev))
-            audio_list = wave                      # the gate / conditioning kernels + feature fusion run in AudioEncoder.forward
+            # equal-length batch: one (graph-captured, with --graph) step; with the gate flags on the front end's kernels head
+            # it - the transcripts enter as the per-clip language features (host: a text operation)
+            lid = s.language_features(text_list, wave.shape[0]).to(dev) if self.gated else None
+            return self.stepper.step(wave, ids, mask, labels.to(dev), lid)
         elif self.aug:
             # ragged clips: the reference's pad-to-longest semantics (one encoder pass per distinct length), eager launches
             audio_list = self.aug.host(audio_list)
         self.opt.zero_grad(set_to_none=True)
         if self.reducer:
-            self.reducer.arm()
+            self.reducer.arm(overlap=False)      # one adapter backward per clip length: buckets are complete only after backward
         a_seq, a_mask = s.audio_encoder(audio_list, text_list)
         t_seq, t_mask = s.text_encoder.forward_ids(ids, mask)
         s._set_precision()

@@ -43,6 +43,22 @@ partners = {
     "GEMM 16384 x 4096 x 1024, output written (134 MB)": lambda: gemm(N),
     "GEMM 16384 x 128 x 1024 x 8 (little output)": lambda: [gemm(128) for _ in range(8)],
 }
+import ctypes as C
+L.lib.ser_debug_clock_probe.restype = C.c_int
+L.lib.ser_debug_clock_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+probe_out = torch.zeros(2 * 8, dtype=torch.int64, device=dev)
+probe_stream = torch.cuda.Stream()
+
+
+def clock_ghz():
+    """shader clock seen by a latency-bound wave right now (8 blocks, ~200 us of dependent FMAs each)"""
+    with torch.cuda.stream(probe_stream):
+        L.check(L.lib.ser_debug_clock_probe(probe_out.data_ptr(), 8, 100000, L.stream_ptr()), "clock probe")
+    probe_stream.synchronize()
+    v = probe_out.cpu().view(8, 2).double()
+    return float((v[:, 0] / v[:, 1]).median() * 0.1)
+
+
 cur = torch.cuda.current_stream()
 NH = 6
 for name, fn in partners.items():
@@ -60,6 +76,16 @@ for name, fn in partners.items():
             st.g_head.replay()
             st.g_opt.replay()
         e1.record(cur)
+        ghz = clock_ghz() if rep == 2 else None          # beside the partner (and the head)
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1) / NH)
-    print(f"{name:56s}: head step {min(ts):.3f} ms (runs {', '.join('%.3f' % t for t in ts)})", flush=True)
+    # clock beside the partner alone
+    if fn is not None:
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                fn()
+    ghz_partner = clock_ghz()
+    torch.cuda.synchronize()
+    print(f"{name:56s}: head step {min(ts):.3f} ms (runs {', '.join('%.3f' % t for t in ts)}); shader clock beside partner + head "
+          f"{ghz:.2f} GHz, beside the partner alone {ghz_partner:.2f} GHz", flush=True)

@@ -93,7 +93,7 @@ def _replica_worker(rank, world, port, tmp, extra, q):
                 super().__init__(*a, **k)
                 made.append(self)
         T.HipEngine = Engine
-        T.main(["--synthetic", "22", "--num_labels", "4", "--epochs", "1", "--batch_size", "4", "--save_dir", os.path.join(tmp, f"ck{rank}"),
+        T.main(["--num_labels", "4", "--epochs", "1", "--batch_size", "4", "--save_dir", os.path.join(tmp, f"ck{rank}"),
                 "--audio_model", os.path.join(tmp, "w2v"), "--text_model", os.path.join(tmp, "xlmr"), "--warmup_ratio", "0.0"] + extra)
         eng = made[0]
         torch.cuda.synchronize()
@@ -108,10 +108,22 @@ def _replica_worker(rank, world, port, tmp, extra, q):
         raise
 
 
-def _two_replicas(tmp_path, extra):
+def _base_width_models(tmp):
+    """Wav2Vec2-Base and XLM-R-Base ARCHITECTURES (768-d, 12 layers, 12 heads, FFN 3072, the 7-layer 512-channel conv
+    front end) with random weights; only the text vocabulary is cut to 2 048 rows so that the two ranks' tables fit a test."""
+    from transformers import Wav2Vec2Config, Wav2Vec2FeatureExtractor, Wav2Vec2Model, XLMRobertaConfig, XLMRobertaModel
+    da, dt = os.path.join(tmp, "w2v"), os.path.join(tmp, "xlmr")
+    torch.manual_seed(3)
+    Wav2Vec2Model(Wav2Vec2Config()).save_pretrained(da)
+    Wav2Vec2FeatureExtractor().save_pretrained(da)
+    XLMRobertaModel(XLMRobertaConfig(vocab_size=2048, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                                     pad_token_id=1, bos_token_id=0, eos_token_id=2)).save_pretrained(dt)
+
+
+def _two_replicas(tmp_path, extra, base_width=False, n="22"):
     from tests.test_gpu_cli import _local_models
     tmp = str(tmp_path)
-    _local_models(tmp)
+    _base_width_models(tmp) if base_width else _local_models(tmp)
     from tokenizers import Tokenizer, models as tkm, pre_tokenizers, processors
     from transformers import PreTrainedTokenizerFast
     vocab = {"<s>": 0, "<pad>": 1, "</s>": 2, "<unk>": 3}
@@ -125,11 +137,11 @@ def _two_replicas(tmp_path, extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, tmp, extra, q)) for r in range(2)]
+    procs = [ctx.Process(target=_replica_worker, args=(r, 2, port, tmp, ["--synthetic", n] + extra, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(600)
+        p.join(900)
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert [r[1] for r in res] == ["ok", "ok"], res
     if res[0][2] != res[1][2]:
@@ -141,7 +153,14 @@ def test_two_ranks_graph_steps_with_ragged_and_equal_batches_stay_identical(tmp_
     """a ragged batch takes the eager path and arms the reducer's per-bucket hooks; a later equal-length
     batch is captured into a graph whose warm-up passes used to fire those hooks (reducing gradients the replay then
     overwrote, and marking the buckets done).  Mixed 3 s / 4 s corpus with --graph: both replicas must end bit-identical."""
-    _two_replicas(tmp_path, ["--synthetic_seconds", "3,4", "--graph", "--no_bucketing"])
+    _two_replicas(tmp_path, ["--synthetic_seconds", "3,4", "--graph", "--epochs", "2"])
+
+
+def test_config4_base_width_two_ranks_augment_graph(tmp_path):
+    """BASELINE config 4 at its own model size: Base-width encoders, 6 classes, 3 s clips (149 frames), --augment, hipGraph
+    steps, two data-parallel ranks (sharing the test box's one GPU over gloo).  17 clips in batches of 4: the last batch is
+    partial, so one rank captures a second graph shape.  Replicas must end bit-identical."""
+    _two_replicas(tmp_path, ["--synthetic_seconds", "3", "--num_labels", "6", "--augment", "--graph"], base_width=True, n="17")
 
 
 def test_two_ranks_with_gates_reduce_the_gate_parameters(tmp_path):

@@ -141,6 +141,48 @@ def test_pipelined_stepping_is_bit_identical_to_sequential(group):
         assert torch.equal(pa, pb), f"{nm}: pipelined stepping diverged from sequential stepping"
 
 
+def test_pipelined_and_graph_stepping_with_the_reference_default_front_end():
+    """The audio encoder's gate flags on (the reference's default AudioEncoder(): quality gates + audio conditioning before
+    Wav2Vec2, their projected features fused into the sequence): the front end's kernels are part of the captured encoder
+    graph (PipelinedStepper) / step graph (TrainStepper), the raw features travel with the batch to the head step.  Same
+    losses and parameters, bit for bit, as eager stepping through the same modules."""
+    import __graft_entry__ as ge
+    from ser_amd.system import PipelinedStepper, TrainStepper
+    dev = torch.device("cuda:0")
+    systems = [ge._small_system(dev, gates=True)[0] for _ in range(3)]
+    for s in systems[1:]:
+        s.load_state_dict(systems[0].state_dict())
+    for s in systems:
+        s.train()
+    assert systems[0].gates_on() and len(systems[0].buckets()) == 8          # the gate bucket is one of them
+    opts = [s.make_optimizer(lr=1e-3) for s in systems]
+    seq = TrainStepper(systems[0], opts[0], use_graph=False)
+    graph = TrainStepper(systems[1], opts[1], use_graph=True)
+    pipe = PipelinedStepper(systems[2], opts[2], group=2)
+    n = 7
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for i in range(n):
+        b = [t.to(dev) for t in _batch(400 + i)]
+        t_ = torch.arange(b[0].shape[1], device=dev) / 16000.0
+        b[0] = b[0] + 0.2 * torch.sin(2 * 3.14159265 * (180.0 + 20 * i) * t_)[None]        # something voiced for the gates to accept
+        batches.append(b)
+    lid = systems[0].language_features(None, batches[0][0].shape[0]).to(dev)
+    seq_losses = [seq.step(*b, lid).item() for b in batches]
+    graph_losses = [graph.step(*b, lid).item() for b in batches]
+    for j in range(pipe.prime):
+        pipe.feed(*batches[j], lid)
+    pipe_losses = [pipe.step(*batches[i], lid).item() for i in range(pipe.prime, n)] + [l.item() for l in pipe.drain()]
+    torch.cuda.synchronize()
+    assert seq_losses == graph_losses, (seq_losses, graph_losses)
+    assert seq_losses == pipe_losses, (seq_losses, pipe_losses)
+    moved = 0
+    for (nm, pa), (_, pb), (_, pc) in zip(*(s.named_parameters() for s in systems)):
+        assert torch.equal(pa, pb) and torch.equal(pa, pc), f"{nm}: stepping paths diverged with the front end on"
+    gate = systems[0].audio_encoder._gate_flat
+    assert gate.gflat.abs().sum().item() > 0, "the gate modules must receive gradients"
+
+
 def test_first_forward_on_busy_streams_keeps_every_parameter():
     """Regression for round 2's rare first-loss mismatch.  The trainable buckets used to be flattened lazily inside the first
     forward; the text-side ones (text adapter, text pooling) on SERSystem's side stream.  Re-pointing `p.data` frees the old
