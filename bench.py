@@ -369,16 +369,34 @@ def main():
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, separate --pmc runs; see profiles/): bench.py cannot run the profiler itself
-        traffic = None
+        traffic = tr_fetch = tr_write = alg_read = alg_write = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
-                traffic = round(json.load(fh)["gemm_bf16"]["hbm_bytes_per_launch"])
+                rec = json.load(fh)["gemm_bf16"]
+            traffic = round(rec["hbm_bytes_per_launch"])
+            tr_fetch, tr_write = round(rec["fetch_bytes_per_launch_corrected"]), round(rec["write_bytes_per_launch"])
         except Exception:  # noqa: BLE001
             traffic = None
+        if pipeline and args.precision == "bf16x3" and not args.stress:
+            # algorithmic operand / result bytes per launch of one grouped encoder pass (split-bf16 planes: 4 B per element
+            # in, 4 B out; the residual of the two N = hidden layer GEMMs is read once): what `traffic` is compared with
+            from ser_amd import _engines as EG
+            acfg = sysm.audio_encoder.engine().cfg
+            nb = args.group * args.batch
+            shp = EG._w2v_gemm_shapes(acfg, nb, int(SR * args.seconds), extra_rows=nb * args.tokens)
+            conv, layer = shp[:-4], shp[-4:]
+            rd = sum(4 * (M * K + N * K) for M, N, K in conv) + acfg.layers * sum(4 * (M * K + N * K) for M, N, K in layer)
+            rd += acfg.layers * 2 * 4 * layer[1][0] * layer[1][1]                     # residual reads (out-proj, FFN2)
+            wr = sum(4 * M * N for M, N, K in conv) + acfg.layers * sum(4 * M * N for M, N, K in layer)
+            nl = len(conv) + 4 * acfg.layers
+            alg_read, alg_write = round(rd / nl), round(wr / nl)
         nprod = 3 if (args.precision == "bf16x3" or args.unfreeze) else 1
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
-                    traffic_source="committed rocprofv3 --pmc passes (profiles/pmc_traffic_latest.json), not this run",
+                    traffic_source="committed rocprofv3 --pmc passes over this command (profiles/pmc_traffic_latest.json), not this run",
+                    traffic_fetch_bytes_per_launch=tr_fetch, traffic_write_bytes_per_launch=tr_write,
+                    algorithmic_read_bytes_per_launch=alg_read, algorithmic_write_bytes_per_launch=alg_write,
+                    read_overfetch=(round(tr_fetch / alg_read, 2) if tr_fetch and alg_read else None),
                     mfma_pipe_utilisation=round(nprod * achieved / PEAK_BF16_TFLOPS, 4),
                     kernel=("gemm_x3_kernel / gemm_x3_group_kernel / gemm_f32_kernel (csrc/gemm_f32.hip: fp32 operands split to bf16 hi+lo on the fly; "
                             "forward, dgrad and wgrad products of encoders and head)" if args.unfreeze else

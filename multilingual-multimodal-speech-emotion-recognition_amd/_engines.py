@@ -236,6 +236,10 @@ def tune_gemm_shapes(shapes, device, reps=8, three_products=False, collective=Fa
     shapes (PipelinedStepper's capture): all ranks time, rank 0's choices are broadcast and installed everywhere."""
     if torch.cuda.is_current_stream_capturing():
         return
+    if os.environ.get("SER_GEMM_TUNE", "0") != "1" and not os.environ.get("SER_GEMM_FORCE_CFG"):
+        # default: no timing pass - the library's deterministic rules pick the tiles (csrc/gemm_bf16.hip pick_bm): the same
+        # kernels on every rank and in every run.  SER_GEMM_TUNE=1 turns the per-shape timing pass back on (experiments).
+        return
     if _world() > 1 and not collective:
         return
     if os.environ.get("SER_GEMM_FORCE_CFG"):      # experiments: one tile configuration for every shape, no timing pass

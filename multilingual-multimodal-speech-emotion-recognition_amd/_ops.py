@@ -132,6 +132,22 @@ class fork:
                 t.record_stream(self.side)
 
 
+# `loss.backward()` without arguments seeds the graph with ones: the fused loss kernel has already written d(loss)/d(inputs)
+# for that seed, so scaling its four gradient tensors by the upstream value (four launches, plus autograd's fill of the
+# seed) is only needed when a caller backpropagates something else through the loss.  The steppers, which always call
+# `loss.backward()` on the loss itself, declare that with this scope.
+_UNIT_LOSS_GRAD = [False]
+
+
+@contextlib.contextmanager
+def unit_loss_grad():
+    prev, _UNIT_LOSS_GRAD[0] = _UNIT_LOSS_GRAD[0], True
+    try:
+        yield
+    finally:
+        _UNIT_LOSS_GRAD[0] = prev
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 

@@ -201,9 +201,8 @@ class _ClassifierFn(torch.autograd.Function):
         dt0 = O.ln_bwd(dh, ln0, ip[1].weight, g(ip[1].weight), g(ip[1].bias), acc)
         O.linear_wgrad(dt0, x, g(ip[0].weight), g(ip[0].bias), acc)
         dx = O.linear_dgrad(dt0, ip[0].weight) if ctx.need_dx else None
-        if not acc:   # anchor branch: defined-but-zero gradients in the reference
-            for p in m._anchor_params:
-                g(p).zero_()
+        # anchor branch: defined-but-zero gradients in the reference.  Nothing ever writes those views of the flat gradient
+        # bucket, which is created zero-filled (models/_flat.py), so they are zeros without a fill launch per parameter and step
         fp.publish()
         ctx.saved = None
         return (None, dx) + (None,) * len(fp.params)
@@ -263,7 +262,10 @@ class AdvancedOpenMaxClassifier(nn.Module):
 
     def forward(self, x: torch.Tensor, use_openmax: bool = True, return_uncertainty: bool = False):
         logits, unc, feats = self._run(x)
-        anchor_loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        z = getattr(self, "_zero_scalar", None)           # the constant 0. of the anchor branch (ref :58-70), one fill per device
+        if z is None or z.device != x.device:
+            self._zero_scalar = z = torch.zeros((), dtype=torch.float32, device=x.device)
+        anchor_loss = z
         if use_openmax and not self.training:
             logits = self.openmax_forward(feats, logits)
         if return_uncertainty:

@@ -470,7 +470,7 @@ class TrainStepper:
     def _fwd_bwd(self, wave, ids, mask, labels, lid=None):
         loss, logits = self.sys.loss(wave, ids, mask, labels, self.use_proto, lid=lid)
         # eager data parallelism reduces a bucket from its module's backward hook, so gradients cannot be deferred there
-        with _ops.defer_wgrads(self.use_graph or self.reducer is None):
+        with _ops.defer_wgrads(self.use_graph or self.reducer is None), _ops.unit_loss_grad():
             loss.backward()
         _ops.wgrad_join()
         return loss.detach(), logits.detach()
@@ -484,7 +484,7 @@ class TrainStepper:
             leaf = fused.detach().requires_grad_()
             logits, unc, _ = s.classifier(leaf, use_openmax=False, return_uncertainty=True)
         loss = s.criterion(logits, unc, leaf, s.prototypes.prototypes, labels, use_proto=self.use_proto)
-        with _ops.defer_wgrads():
+        with _ops.defer_wgrads(), _ops.unit_loss_grad():
             loss.backward()
         _ops.wgrad_join()
         self._fused, self._dfused = fused, leaf.grad
@@ -792,7 +792,7 @@ class PipelinedStepper:
         s = self.sys
         loss, logits, fused, leaf = s.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels,
                                                         self.use_proto, split=True, gate_features=self._gate_features())
-        with _ops.defer_wgrads():
+        with _ops.defer_wgrads(), _ops.unit_loss_grad():
             loss.backward()
         _ops.wgrad_join()
         self._fused, self._dfused = fused, leaf.grad
@@ -811,7 +811,7 @@ class PipelinedStepper:
             return out
         loss, logits = self.sys.loss_from_encoded(self.enc_cur[0], self.enc_cur[1], self.cur_mask, self.cur_labels, self.use_proto,
                                                   gate_features=self._gate_features())
-        with _ops.defer_wgrads():
+        with _ops.defer_wgrads(), _ops.unit_loss_grad():
             loss.backward()
         _ops.wgrad_join()
         return loss.detach(), logits.detach()
