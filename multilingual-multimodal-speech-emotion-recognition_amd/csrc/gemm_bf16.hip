@@ -705,14 +705,14 @@ static int pick_bm(long long rows_a, long long rows_b, int N, int K, long long n
   if (g_gemm_force_bm) return g_gemm_force_bm;
   for (const auto& h : g_tile_hints)
     if (h.rows == rows_a + rows_b * nb_b && h.N == N && h.K == K && h.mode == mode && h.cfg) return h.cfg;
-  // Interleaved three-product mode with at least one full round of 128 x 128 tiles (a grouped encoder pass: 7 392+ rows):
+  // Interleaved three-product mode with (nearly) a full round of 128 x 128 tiles or more (a grouped encoder pass: 7 392+ rows):
   // the single-LDS-buffer 128 x 128 form, three workgroups per CU.  Stand-alone it is the fastest or within a few percent of
   // it on every shape of the pass (scripts/gemm_cfg_probe.py, profiles/r03_*), and beside the head it is the better citizen
   // (34 KB of LDS per workgroup, 58 KB of every CU left to the other queues): 0.129 of peak in situ against 0.119-0.122 for
   // plans picked by stand-alone timings.  Deterministic: every rank and every run launches the same kernels.
   if (mode == M_X3I) {
     const long long t128 = ((rows_a + 127) / 128 + ((rows_b + 127) / 128) * nb_b) * ((N + 127) / 128);
-    if (t128 >= 768) return SER_GEMM_CFG_SINGLE + 128;
+    if (t128 >= 640) return SER_GEMM_CFG_SINGLE + 128;
   }
   const int cands[5] = {64, 96, 128, 160, 192};
   const int slots[5] = {slots_per_cu<64>(), slots_per_cu<96>(), slots_per_cu<128>(), slots_per_cu<160>(), slots_per_cu<192>()};
