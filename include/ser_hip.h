@@ -206,6 +206,14 @@ int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, l
  * folds the bias gradient (column sums of dy) into the same pass. */
 int ser_linear_fwd(const float* x, const float* W, const float* bias, int act, const float* residual, int ldr,
                    float* y, int M, int N, int K, void* stream);
+/* The same for nprob independent problems of one dependency level in ONE launch (e.g. the six first-level projections of the
+ * two directions of ref cross_attention.py:15-17,22-24; both adapters of ref audio_encoder.py:112 / text_encoder.py:57).
+ * ptrs: 5 per problem {x, W, bias | NULL, residual | NULL, y}; dims: 5 per problem {M, N, K, act, ldr}.  Results are
+ * bit-identical to nprob calls of ser_linear_fwd. */
+int ser_linear_fwd_group(const void* const* ptrs, const int* dims, int nprob, void* stream);
+/* dx_i[M,K] (+)= dy_i[M,N] W_i[N,K] for nprob problems.  ptrs: 3 per problem {dy, W, dx}; dims: 4 per problem
+ * {M, N, K, accumulate}.  Bit-identical to nprob calls of ser_linear_dgrad (without a ReLU mask). */
+int ser_linear_dgrad_group(const void* const* ptrs, const int* dims, int nprob, void* stream);
 /* up to 32 token-level (M > 16) weight gradients, split over their token dimension, in one GEMM launch + one
  * reduce launch; ptrs = host array {dy, x, dW, db} per problem, dims = host array {M, N, K} per problem */
 size_t ser_linear_wgrad_group_workspace_bytes(const int* dims, int nprob);

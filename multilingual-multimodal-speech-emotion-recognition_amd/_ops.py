@@ -95,6 +95,12 @@ def wgrad_join():
 # SIDE_STREAMS = False runs them inline on the caller's stream (same arithmetic either way).
 import os as _os
 SIDE_STREAMS = _os.environ.get("SER_SIDE_STREAMS", "1") == "1"
+# GROUPED_HEAD: the alternative to the side stream - the independent products of one dependency level (both cross-attention
+# directions, both adapters, both poolings) as ONE grouped launch each (ser_linear_fwd_group / ser_linear_dgrad_group) on one
+# stream.  Measured (profiles/r03_b_grouped_head.txt): 2 % faster with the head alone on the chip, 4-6 % SLOWER beside the
+# encoder pass - two queues get the head a larger share of a contended chip than one queue with wider launches - so it is
+# off by default.
+GROUPED_HEAD = _os.environ.get("SER_HEAD_GROUPED", "0") == "1"
 
 
 class fork:
@@ -164,6 +170,51 @@ def linear_fwd(x, W, b=None, act=ACT_NONE, residual=None, out=None):
     L.check(L.lib.ser_linear_fwd(L.ptr(x), L.ptr(W), L.ptr(b), act, L.ptr(residual), N, L.ptr(y), M, N, K, L.stream_ptr()),
             "ser_linear_fwd")
     return y
+
+
+L._sig("ser_linear_fwd_group", L.i32, L.vp, L.vp, L.i32, L.vp)
+L._sig("ser_linear_dgrad_group", L.i32, L.vp, L.vp, L.i32, L.vp)
+
+
+def linear_fwd_group(problems):
+    """Independent Linear layers of one dependency level in ONE launch.  problems: list of (x, W, b | None, act, residual | None)
+    -> list of y.  Bit-identical to linear_fwd called per problem."""
+    import ctypes as C
+    n = len(problems)
+    ptrs = (C.c_void_p * (5 * n))()
+    dims = (C.c_int * (5 * n))()
+    outs = []
+    for i, (x, W, b, act, res) in enumerate(problems):
+        M, K = x.shape
+        N = W.shape[0]
+        assert x.is_contiguous() and W.is_contiguous() and W.shape[1] == K
+        y = empty(M, N, like=x)
+        outs.append(y)
+        ptrs[5 * i], ptrs[5 * i + 1], ptrs[5 * i + 2], ptrs[5 * i + 3], ptrs[5 * i + 4] = L.ptr(x), L.ptr(W), L.ptr(b), L.ptr(res), L.ptr(y)
+        dims[5 * i], dims[5 * i + 1], dims[5 * i + 2], dims[5 * i + 3], dims[5 * i + 4] = M, N, K, int(act), N
+    L.check(L.lib.ser_linear_fwd_group(ptrs, dims, n, L.stream_ptr()), "ser_linear_fwd_group")
+    return outs
+
+
+def linear_dgrad_group(problems):
+    """Input gradients of independent Linear layers in ONE launch.  problems: list of (dy, W, out | None, accumulate) ->
+    list of dx (`out` is written / accumulated into when given).  Bit-identical to linear_dgrad called per problem."""
+    import ctypes as C
+    n = len(problems)
+    ptrs = (C.c_void_p * (3 * n))()
+    dims = (C.c_int * (4 * n))()
+    outs = []
+    for i, (dy, W, out, acc) in enumerate(problems):
+        M, N = dy.shape
+        K = W.shape[1]
+        assert dy.is_contiguous() and W.shape[0] == N
+        dx = out if out is not None else empty(M, K, like=dy)
+        assert dx.is_contiguous() or dx.stride(-1) == 1
+        outs.append(dx)
+        ptrs[3 * i], ptrs[3 * i + 1], ptrs[3 * i + 2] = L.ptr(dy), L.ptr(W), L.ptr(dx)
+        dims[4 * i], dims[4 * i + 1], dims[4 * i + 2], dims[4 * i + 3] = M, N, K, 1 if acc else 0
+    L.check(L.lib.ser_linear_dgrad_group(ptrs, dims, n, L.stream_ptr()), "ser_linear_dgrad_group")
+    return outs
 
 
 def linear_dgrad(dy, W, out=None, accumulate=False, relu_mask=None):

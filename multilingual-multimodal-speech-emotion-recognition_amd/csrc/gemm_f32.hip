@@ -793,6 +793,28 @@ __global__ __launch_bounds__(256) void gemm_x3_group_kernel(const WgradGroup G) 
   x3_body<0, 0, NP>(g, blockIdx.x, blockIdx.y, (int)blockIdx.z - P.z0, lds);
 }
 
+// Independent token-level products of one dependency level in ONE launch (forward: the six first-level projections of the
+// two cross-attention directions, both adapters, ...; backward: their input gradients).  The head used to run its two
+// directions on two streams; the join between the two hardware queues costs 50-200 us per fork under load
+// (profiles/r03_a_head_step_kernel_sequence.txt), more than the kernels themselves.  Same tile code and the same
+// summation order as gemm_x3_kernel: a problem's result does not depend on what it is grouped with.
+constexpr int SER_X3_MULTI = 8;
+struct X3Multi {
+  SerGemmF32Args p[SER_X3_MULTI];
+  int start[SER_X3_MULTI + 1];     // first block of problem i in the flattened grid (tiles_n x tiles_m each)
+  int nprob;
+};
+template <int AKF, int BKF, int NP>
+__global__ __launch_bounds__(256) void gemm_x3_multi_kernel(const X3Multi G) {
+  __shared__ __attribute__((aligned(16))) char lds[2][(NP == 3 ? 4 : 2) * X3_PLANE];
+  int pi = 0;
+  for (int i = 1; i < G.nprob; ++i)
+    if ((int)blockIdx.x >= G.start[i]) pi = i;
+  const SerGemmF32Args& g = G.p[pi];
+  const int t = (int)blockIdx.x - G.start[pi], tn = (g.N + 63) / 64;
+  x3_body<AKF, BKF, NP>(g, t % tn, t / tn, 0, lds);
+}
+
 struct ReduceGroupProb {
   const float *ws, *ws_rowsum;
   float *dW, *db;
@@ -1036,6 +1058,72 @@ extern "C" int ser_linear_dgrad(const float* dy, const float* W, const float* re
     return ser_act_bwd(dx, relu_mask, SER_ACT_RELU, (long long)M * K, dx, stream);
   }
   return SER_OK;
+}
+
+// ---- grouped token-level products (one launch per dependency level) --------------------------------------------------
+static bool x3_multi_ok(const SerGemmF32Args& g) {
+  return g_use_x3 && g.vec_a && g.vec_b && (g.K % X3_BK) == 0 && g.M > 16 && g.N >= 4 && g.sak == 1;
+}
+template <int BKF>
+static int launch_x3_multi(SerGemmF32Args* probs, int n, int products, hipStream_t st) {
+  for (int i0 = 0; i0 < n; i0 += SER_X3_MULTI) {
+    X3Multi G;
+    memset(&G, 0, sizeof(G));
+    G.nprob = n - i0 < SER_X3_MULTI ? n - i0 : SER_X3_MULTI;
+    int blocks = 0;
+    for (int i = 0; i < G.nprob; ++i) {
+      G.p[i] = probs[i0 + i];
+      G.start[i] = blocks;
+      blocks += ceil_div(G.p[i].M, 64) * ceil_div(G.p[i].N, 64);
+    }
+    G.start[G.nprob] = blocks;
+    if (products == 1) hipLaunchKernelGGL((gemm_x3_multi_kernel<1, BKF, 1>), dim3(blocks), dim3(256), 0, st, G);
+    else hipLaunchKernelGGL((gemm_x3_multi_kernel<1, BKF, 3>), dim3(blocks), dim3(256), 0, st, G);
+    SER_LAUNCH_CHECK();
+  }
+  return SER_OK;
+}
+
+// y_i[M,N] = act_i(x_i[M,K] W_i[N,K]^T + b_i) + residual_i for nprob independent problems.
+// ptrs: 5 per problem {x, W, bias | null, residual | null, y}; dims: 5 per problem {M, N, K, act, ldr}.
+// Problems the split-bf16 tile kernel cannot take (M <= 16, N < 4, K % 64 != 0, unaligned) are launched on their own.
+extern "C" int ser_linear_fwd_group(const void* const* ptrs, const int* dims, int nprob, void* stream) {
+  SER_REQUIRE(ptrs && dims && nprob >= 1 && nprob <= 64, "linear_fwd_group: bad arguments");
+  SerGemmF32Args grp[64];
+  int ng = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const float* x = (const float*)ptrs[5 * i]; const float* W = (const float*)ptrs[5 * i + 1];
+    const float* b = (const float*)ptrs[5 * i + 2]; const float* r = (const float*)ptrs[5 * i + 3]; float* y = (float*)ptrs[5 * i + 4];
+    const int M = dims[5 * i], N = dims[5 * i + 1], K = dims[5 * i + 2], act = dims[5 * i + 3], ldr = dims[5 * i + 4];
+    SER_REQUIRE(x && W && y && M > 0 && N > 0 && K > 0, "linear_fwd_group: problem %d is empty", i);
+    SerGemmF32Args g;
+    g.a = x; g.b = W; g.c = y; g.M = M; g.N = N; g.K = K; g.sam = K; g.sak = 1; g.sbk = 1; g.sbn = K; g.ldc = N;
+    g.bias = b; g.act = act; g.residual = r; g.ldr = ldr; g.accumulate = 0; g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr;
+    g.vec_a = vec_ok(x, 1, K, K) ? 1 : 0; g.vec_b = vec_ok(W, 1, K, K) ? 1 : 0; g.products = 3;
+    if (x3_multi_ok(g)) grp[ng++] = g;
+    else SER_TRY(ser_linear_fwd(x, W, b, act, r, ldr, y, M, N, K, stream));
+  }
+  return ng ? launch_x3_multi<1>(grp, ng, 3, (hipStream_t)stream) : SER_OK;
+}
+
+// dx_i[M,K] (+)= dy_i[M,N] W_i[N,K].  ptrs: 3 per problem {dy, W, dx}; dims: 4 per problem {M, N, K, accumulate}.
+extern "C" int ser_linear_dgrad_group(const void* const* ptrs, const int* dims, int nprob, void* stream) {
+  SER_REQUIRE(ptrs && dims && nprob >= 1 && nprob <= 64, "linear_dgrad_group: bad arguments");
+  SerGemmF32Args grp[64];
+  int ng = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const float* dy = (const float*)ptrs[3 * i]; const float* W = (const float*)ptrs[3 * i + 1]; float* dx = (float*)ptrs[3 * i + 2];
+    const int M = dims[4 * i], N = dims[4 * i + 1], K = dims[4 * i + 2], accumulate = dims[4 * i + 3];
+    SER_REQUIRE(dy && W && dx && M > 0 && N > 0 && K > 0, "linear_dgrad_group: problem %d is empty", i);
+    SerGemmF32Args g;   // C[M,K] = A[M,N] . B[N,K]: A = dy (k = n contiguous), B = W rows (column index contiguous)
+    g.a = dy; g.b = W; g.c = dx; g.M = M; g.N = K; g.K = N; g.sam = N; g.sak = 1; g.sbk = K; g.sbn = 1; g.ldc = K;
+    g.bias = nullptr; g.act = SER_ACT_NONE; g.residual = nullptr; g.ldr = 0; g.accumulate = accumulate; g.k_chunk = 0;
+    g.ws = nullptr; g.ws_rowsum = nullptr;
+    g.vec_a = vec_ok(dy, 1, N, N) ? 1 : 0; g.vec_b = vec_ok(W, 1, K, K) ? 1 : 0; g.products = g_head_bwd_products;
+    if (x3_multi_ok(g)) grp[ng++] = g;
+    else SER_TRY(ser_linear_dgrad(dy, W, nullptr, dx, M, N, K, accumulate, stream));
+  }
+  return ng ? launch_x3_multi<0>(grp, ng, g_head_bwd_products, (hipStream_t)stream) : SER_OK;
 }
 
 // Up to SER_WGRAD_BATCH skinny weight gradients in ONE launch (problem index = blockIdx.z): the 70 weight gradients

@@ -121,6 +121,103 @@ class _CrossFn(torch.autograd.Function):
         return (None, da.view(B, Sa, Da), dt.view(B, St, Dt), None, None) + (None,) * len(fp.params)
 
 
+def _dirs(m):
+    """Per direction (A <- T, T <- A): the Linear / attention / norm modules of ref cross_attention.py:15-26."""
+    return ((m.q_a, m.k_t, m.v_t, m.attn_a, m.out_a, m.norm_a), (m.q_t, m.k_a, m.v_a, m.attn_t, m.out_t, m.norm_t))
+
+
+class _CrossGroupedFn(torch.autograd.Function):
+    """Both directions of ref cross_attention.py:32-53 as ONE autograd node whose independent products go out level by level
+    in grouped launches (`O.linear_fwd_group` / `O.linear_dgrad_group`): 6 + 6 + 2 + 2 Linear layers forward are four launches,
+    not sixteen on two streams.  (Round 2 ran the two directions on two streams; a join between two hardware queues costs
+    50-200 us under load, more than the kernels it overlapped: profiles/r03_a_head_step_kernel_sequence.txt.)"""
+
+    @staticmethod
+    def forward(ctx, m, a, t, a_mask, t_mask, *params):
+        B, Sa, Da = a.shape
+        St, Dt = t.shape[1], t.shape[2]
+        a2, t2 = a.reshape(B * Sa, Da).contiguous(), t.reshape(B * St, Dt).contiguous()
+        am = a_mask.to(torch.float32).contiguous() if a_mask is not None else None
+        tm = t_mask.to(torch.float32).contiguous() if t_mask is not None else None
+        (qa, kt, vt, mha_a, out_a, norm_a), (qt, ka, va, mha_t, out_t, norm_t) = _dirs(m)
+        E = qa.weight.shape[0]
+        N_ = O.ACT_NONE
+        # level 1: the six projections into the shared space (ref :15-17, :22-24)
+        q1a, k1t, v1t, q1t, k1a, v1a = O.linear_fwd_group([
+            (a2, qa.weight, qa.bias, N_, None), (t2, kt.weight, kt.bias, N_, None), (t2, vt.weight, vt.bias, N_, None),
+            (t2, qt.weight, qt.bias, N_, None), (a2, ka.weight, ka.bias, N_, None), (a2, va.weight, va.bias, N_, None)])
+        # level 2: nn.MultiheadAttention's packed in-projection (torch nn/functional.py:6576-6603)
+        Wa, ba, Wt, bt = mha_a.in_proj_weight, mha_a.in_proj_bias, mha_t.in_proj_weight, mha_t.in_proj_bias
+        Qa, Ka, Va, Qt, Kt, Vt = O.linear_fwd_group([
+            (q1a, Wa[:E], ba[:E], N_, None), (k1t, Wa[E:2 * E], ba[E:2 * E], N_, None), (v1t, Wa[2 * E:], ba[2 * E:], N_, None),
+            (q1t, Wt[:E], bt[:E], N_, None), (k1a, Wt[E:2 * E], bt[E:2 * E], N_, None), (v1a, Wt[2 * E:], bt[2 * E:], N_, None)])
+        sites = m._drop_sites                       # output a, output t, attention a, attention t
+        d_attn_a, d_attn_t = O.dropout_ctx(mha_a.dropout), O.dropout_ctx(mha_t.dropout)      # ref :18,25
+        ctx_a, Pa = O.xattn_fwd(Qa, Ka, Va, tm, B, Sa, St, m.num_heads, d_attn_a, sites[2])
+        ctx_t, Pt = O.xattn_fwd(Qt, Kt, Vt, am, B, St, Sa, m.num_heads, d_attn_t, sites[3])
+        c2a, c2t = O.linear_fwd_group([(ctx_a, mha_a.out_proj.weight, mha_a.out_proj.bias, N_, None),
+                                       (ctx_t, mha_t.out_proj.weight, mha_t.out_proj.bias, N_, None)])
+        oa, ot = O.linear_fwd_group([(c2a, out_a.weight, out_a.bias, N_, None), (c2t, out_t.weight, out_t.bias, N_, None)])
+        d_out = O.dropout_ctx(m.dropout.p)                                                   # ref :43,51: self.dropout(out)
+        O.dropout_(oa, d_out, sites[0])
+        O.dropout_(ot, d_out, sites[1])
+        ya, lna = O.ln_fwd(a2, norm_a.weight, norm_a.bias, 1e-5, x2=oa)
+        yt, lnt = O.ln_fwd(t2, norm_t.weight, norm_t.bias, 1e-5, x2=ot)
+        ctx.m, ctx.dims = m, (B, Sa, St, Da, Dt)
+        ctx.saved = (a2, t2, q1a, k1t, v1t, q1t, k1a, v1a, Qa, Ka, Va, Qt, Kt, Vt, Pa, Pt, ctx_a, ctx_t, c2a, c2t, lna, lnt,
+                     d_attn_a, d_attn_t, d_out)
+        return ya.view(B, Sa, Da), yt.view(B, St, Dt)
+
+    @staticmethod
+    def backward(ctx, dya, dyt):
+        m = ctx.m
+        B, Sa, St, Da, Dt = ctx.dims
+        (a2, t2, q1a, k1t, v1t, q1t, k1a, v1a, Qa, Ka, Va, Qt, Kt, Vt, Pa, Pt, ctx_a, ctx_t, c2a, c2t, lna, lnt,
+         d_attn_a, d_attn_t, d_out) = ctx.saved
+        (qa, kt, vt, mha_a, out_a, norm_a), (qt, ka, va, mha_t, out_t, norm_t) = _dirs(m)
+        fp = m._flat
+        acc = fp.accumulating()
+        g = fp.gview
+        E = qa.weight.shape[0]
+        sites = m._drop_sites
+        dya2, dyt2 = dya.reshape(B * Sa, Da).contiguous(), dyt.reshape(B * St, Dt).contiguous()
+        # LayerNorm backward; its input gradient is both the residual branch (first term of da / dt) and, after the output
+        # dropout, the gradient of the block output
+        dza = O.ln_bwd(dya2, lna, norm_a.weight, g(norm_a.weight), g(norm_a.bias), acc)
+        dzt = O.ln_bwd(dyt2, lnt, norm_t.weight, g(norm_t.weight), g(norm_t.bias), acc)
+        # (a copy, always: dza / dzt stay operands of weight-gradient launches that may be deferred to the end of backward,
+        # while da / dt are accumulated into below)
+        da, dt = dza.clone(), dzt.clone()
+        O.dropout_(dza, d_out, sites[0])
+        O.dropout_(dzt, d_out, sites[1])
+        O.linear_wgrad(dza, c2a, g(out_a.weight), g(out_a.bias), acc)
+        O.linear_wgrad(dzt, c2t, g(out_t.weight), g(out_t.bias), acc)
+        dc2a, dc2t = O.linear_dgrad_group([(dza, out_a.weight, None, False), (dzt, out_t.weight, None, False)])
+        O.linear_wgrad(dc2a, ctx_a, g(mha_a.out_proj.weight), g(mha_a.out_proj.bias), acc)
+        O.linear_wgrad(dc2t, ctx_t, g(mha_t.out_proj.weight), g(mha_t.out_proj.bias), acc)
+        dctx_a, dctx_t = O.linear_dgrad_group([(dc2a, mha_a.out_proj.weight, None, False), (dc2t, mha_t.out_proj.weight, None, False)])
+        dQa, dKa, dVa = O.xattn_bwd(dctx_a, Qa, Ka, Va, Pa, B, Sa, St, m.num_heads, d_attn_a, sites[2])
+        dQt, dKt, dVt = O.xattn_bwd(dctx_t, Qt, Kt, Vt, Pt, B, St, Sa, m.num_heads, d_attn_t, sites[3])
+        Wa, Wt = mha_a.in_proj_weight, mha_t.in_proj_weight
+        gWa, gba, gWt, gbt = g(Wa), g(mha_a.in_proj_bias), g(Wt), g(mha_t.in_proj_bias)
+        for dX, x1, gW, gb, lo in ((dQa, q1a, gWa, gba, 0), (dKa, k1t, gWa, gba, E), (dVa, v1t, gWa, gba, 2 * E),
+                                   (dQt, q1t, gWt, gbt, 0), (dKt, k1a, gWt, gbt, E), (dVt, v1a, gWt, gbt, 2 * E)):
+            O.linear_wgrad(dX, x1, gW[lo:lo + E], gb[lo:lo + E], acc)
+        dq1a, dk1t, dv1t, dq1t, dk1a, dv1a = O.linear_dgrad_group([
+            (dQa, Wa[:E], None, False), (dKa, Wa[E:2 * E], None, False), (dVa, Wa[2 * E:], None, False),
+            (dQt, Wt[:E], None, False), (dKt, Wt[E:2 * E], None, False), (dVt, Wt[2 * E:], None, False)])
+        for dX, x, lin in ((dq1a, a2, qa), (dk1t, t2, kt), (dv1t, t2, vt), (dq1t, t2, qt), (dk1a, a2, ka), (dv1a, a2, va)):
+            O.linear_wgrad(dX, x, g(lin.weight), g(lin.bias), acc)
+        # input gradients: three contributions each for the audio and the text sequence, accumulated into the residual term
+        # (two problems of one launch never write the same buffer)
+        O.linear_dgrad_group([(dq1a, qa.weight, da, True), (dq1t, qt.weight, dt, True)])
+        O.linear_dgrad_group([(dk1a, ka.weight, da, True), (dk1t, kt.weight, dt, True)])
+        O.linear_dgrad_group([(dv1a, va.weight, da, True), (dv1t, vt.weight, dt, True)])
+        fp.publish()
+        ctx.saved = None
+        return (None, da.view(B, Sa, Da), dt.view(B, St, Dt), None, None) + (None,) * len(fp.params)
+
+
 class CrossModalAttention(nn.Module):
     def __init__(self, audio_dim: int, text_dim: int, shared_dim: int = 256, num_heads: int = 8, dropout: float = 0.1):
         super().__init__()
@@ -146,4 +243,5 @@ class CrossModalAttention(nn.Module):
     def forward(self, audio_seq: torch.Tensor, text_seq: torch.Tensor, audio_mask: Optional[torch.Tensor] = None,
                 text_mask: Optional[torch.Tensor] = None):
         self._flat.ensure()
-        return _CrossFn.apply(self, audio_seq, text_seq, audio_mask, text_mask, *self._flat.params)
+        fn = _CrossGroupedFn if O.GROUPED_HEAD else _CrossFn
+        return fn.apply(self, audio_seq, text_seq, audio_mask, text_mask, *self._flat.params)

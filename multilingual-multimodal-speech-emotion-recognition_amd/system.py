@@ -136,13 +136,10 @@ class SERSystem(nn.Module):
         if self.gates_on():
             wave, q_raw, c_raw = self.front_end(wave, lid)
         a_enc, t_enc = self.encode_frozen(wave, ids.to(wave.device), attn_mask.to(wave.device))
-        with _ops.fork(self._side_stream()) as f:
-            t_seq = adapter_apply(self.text_encoder, t_enc)
-        a_seq = adapter_apply(self.audio_encoder, a_enc)
+        a_seq, t_seq = self._adapters(a_enc, t_enc)
         if q_raw is not None or c_raw is not None:
             a_seq = self.audio_encoder.fuse_gate_features(a_seq, q_raw, c_raw)
         a_mask = self._ones_mask(a_seq)
-        f.join(produced=[t_seq], consumed=[t_enc])
         return a_seq, a_mask, t_seq, attn_mask.to(device=a_seq.device, dtype=torch.float32)
 
     def _ones_mask(self, seq):
@@ -153,6 +150,17 @@ class SERSystem(nn.Module):
         if m is None or m[0] != key:
             self._mask_cache = m = (key, torch.ones(seq.shape[0], seq.shape[1], dtype=torch.float32, device=seq.device))
         return m[1]
+
+    def _adapters(self, a_enc, t_enc):
+        """Both residual adapters (independent): the text one on the side stream, or - GROUPED_HEAD - one grouped launch per level."""
+        from .models.adapter import adapter_apply, adapters_apply
+        if _ops.GROUPED_HEAD:
+            return adapters_apply(self.audio_encoder, self.text_encoder, a_enc, t_enc)
+        with _ops.fork(self._side_stream()) as f:
+            t_seq = adapter_apply(self.text_encoder, t_enc)
+        a_seq = adapter_apply(self.audio_encoder, a_enc)
+        f.join(produced=[t_seq], consumed=[t_enc])
+        return a_seq, t_seq
 
     def _side_stream(self):
         if self._side is None:
@@ -229,12 +237,9 @@ class SERSystem(nn.Module):
         self.prepare()
         self._set_precision()
         with self._dropout_scope():
-            with _ops.fork(self._side_stream()) as f:
-                t_seq = adapter_apply(self.text_encoder, t_enc)
-            a_seq = adapter_apply(self.audio_encoder, a_enc)
+            a_seq, t_seq = self._adapters(a_enc, t_enc)
             if gate_features is not None and (gate_features[0] is not None or gate_features[1] is not None):
                 a_seq = self.audio_encoder.fuse_gate_features(a_seq, gate_features[0], gate_features[1])
-            f.join(produced=[t_seq], consumed=[t_enc])
             a_mask = self._ones_mask(a_seq)
             fused = self.head(a_seq, a_mask, t_seq, attn_mask.to(torch.float32))
             leaf = fused.detach().requires_grad_() if split else fused
@@ -249,6 +254,12 @@ class SERSystem(nn.Module):
         a_enh, t_enh = self.cross(a_seq, t_seq, a_mask, t_mask)
         # the two poolings are independent: text pooling (forward, and therefore its backward, which autograd runs
         # on the forward's stream) goes to the side stream
+        if _ops.GROUPED_HEAD:
+            from .models.pooling import pools_apply
+            a_vec, t_vec = pools_apply(self.pool_a, self.pool_t, a_enh, a_mask, t_enh, t_mask)      # grouped launches, one stream
+            return self.fusion(a_vec, t_vec)
+        # the two poolings are independent: text pooling (forward, and therefore its backward, which autograd runs on the
+        # forward's stream) goes to the side stream
         with _ops.fork(self._side_stream()) as f:
             t_vec = self.pool_t(t_enh, t_mask)
         a_vec = self.pool_a(a_enh, a_mask)

@@ -183,6 +183,38 @@ def test_pipelined_and_graph_stepping_with_the_reference_default_front_end():
     assert gate.gflat.abs().sum().item() > 0, "the gate modules must receive gradients"
 
 
+def test_grouped_head_launches_match_the_two_stream_head():
+    """`_ops.GROUPED_HEAD` (off by default: slower beside the encoder pass): both cross-attention directions, both adapters and
+    both poolings as grouped launches on one stream (ser_linear_fwd_group / ser_linear_dgrad_group).  Same tile code per
+    problem: the forward - and with it the loss - is bit-identical to the two-stream head; gradients agree to fp32 rounding
+    (the three input-gradient contributions of a sequence are accumulated in a different order)."""
+    import __graft_entry__ as ge
+    from ser_amd import _ops as OP
+    dev = torch.device("cuda:0")
+    sys_a, _, _ = ge._small_system(dev, train_dropout=True)
+    sys_b, _, _ = ge._small_system(dev, train_dropout=True)
+    sys_b.load_state_dict(sys_a.state_dict())
+    sys_a.train(); sys_b.train()
+    batch = [t.to(dev) for t in _batch(31)]
+    la, _ = sys_a.loss(*batch)
+    la.backward()
+    prev = OP.GROUPED_HEAD
+    OP.GROUPED_HEAD = True
+    try:
+        lb, _ = sys_b.loss(*batch)
+        lb.backward()
+    finally:
+        OP.GROUPED_HEAD = prev
+    torch.cuda.synchronize()
+    assert la.item() == lb.item()
+    for (n, pa), (_, pb) in zip(sys_a.named_parameters(), sys_b.named_parameters()):
+        if pa.grad is None:
+            assert pb.grad is None, n
+            continue
+        scale = max(pa.grad.abs().max().item(), 1e-12)
+        assert (pa.grad - pb.grad).abs().max().item() <= 2e-5 * scale, f"{n}: grouped head gradient differs"
+
+
 def test_first_forward_on_busy_streams_keeps_every_parameter():
     """Regression for round 2's rare first-loss mismatch.  The trainable buckets used to be flattened lazily inside the first
     forward; the text-side ones (text adapter, text pooling) on SERSystem's side stream.  Re-pointing `p.data` frees the old
