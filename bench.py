@@ -119,7 +119,8 @@ def cpu_baseline_and_parity(sample, sysm, wc, xc, args):
     Bc = wave.shape[0]
     a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
     tr = OracleTrainer(sample["sds"], a_cfg, t_cfg, num_layers=35, heads=8, num_labels=sysm.num_labels,
-                       dropout_seed=sysm.dropout_seed if sysm.train_dropout else None)      # same train-mode step as the HIP path
+                       dropout_seed=sysm.dropout_seed if sysm.train_dropout else None,      # same train-mode step as the HIP path
+                       train_encoders=bool(args.unfreeze))                                   # config 3: gradients and AdamW for the encoders too
     ref = tr.forward(list(wave), ids, mask, use_openmax=False, training=True)
     err = (sample["logits"] - ref["logits"]).abs().max().item()
     same = bool(torch.equal(sample["logits"].argmax(1), ref["logits"].argmax(1)))
@@ -127,7 +128,7 @@ def cpu_baseline_and_parity(sample, sysm, wc, xc, args):
     times = time_steps(tr, list(wave), ids, mask, labels, warmup=args.cpu_warmup, steps=args.cpu_steps, budget_s=args.cpu_budget)
     sec = sorted(times)[len(times) // 2]
     base = dict(value=round(Bc / sec, 4), unit="utt/s", cores=cores, kind="port", cpu_model=model,
-                sample=f"median of {len(times)} timed train steps after {args.cpu_warmup} warm-up (fwd+loss+bwd+AdamW, head dropout on) of "
+                sample=f"median of {len(times)} timed {'full fine-tune ' if args.unfreeze else ''}train steps after {args.cpu_warmup} warm-up (fwd+loss+bwd+AdamW, head dropout on) of "
                        f"oracle/cpu_step.py at batch {Bc}, {args.seconds:g} s audio + {args.tokens} tokens, PyTorch-CPU fp32, "
                        f"{cores} threads = physical cores available to the process ({model})")
     return base, err, same, spread
@@ -289,14 +290,15 @@ def main():
     if args.front_end:
         args.no_cpu_baseline = True                # the oracle's timed step has no front end; its kernels are pinned by tests/test_gpu_frontend.py
     sysm.dropout_seed += rank                      # every data-parallel rank draws its own dropout masks
+    sysm.train()
+    sample = None
+    if args.unfreeze:
+        args.cpu_batch = args.batch                # the CPU baseline times the same full fine-tune step at the same batch
+    if rank == 0 and not args.no_cpu_baseline:
+        sample = parity_sample(sysm, xc, args, dev)      # on the initial weights, before any optimizer step (no encoder noise: parity definition)
     if args.unfreeze:                              # the encoders' own training-mode noise, as the reference's .train() gives it
         for m in (sysm.audio_encoder, sysm.text_encoder):
             m.encoder_train_noise, m.noise_seed = True, rank
-    sysm.train()
-    sample = None
-    from ser_amd import _engines as E
-    if rank == 0 and not args.no_cpu_baseline:
-        sample = parity_sample(sysm, xc, args, dev)      # on the initial weights, before any optimizer step
     opt = sysm.make_optimizer(lr=1e-4)
     reducer = GradReducer(sysm) if world > 1 else None
     # LayerDrop changes which kernels run from step to step (a host decision, as in HF): the fine-tune configuration steps eagerly
@@ -390,7 +392,7 @@ def main():
             wr = sum(4 * M * N for M, N, K in conv) + acfg.layers * sum(4 * M * N for M, N, K in layer)
             nl = len(conv) + 4 * acfg.layers
             alg_read, alg_write = round(rd / nl), round(wr / nl)
-        nprod = 3 if (args.precision == "bf16x3" or args.unfreeze) else 1
+        nprod = 3 if args.precision == "bf16x3" else 1
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                     traffic_source="committed rocprofv3 --pmc passes over this command (profiles/pmc_traffic_latest.json), not this run",
@@ -439,7 +441,11 @@ def main():
                                       "Large-sized (1024-d, 24-layer) Wav2Vec2 + XLM-R" if args.stress else "Wav2Vec2-Base + XLM-R-Base",
                                       "trained too (full fine-tune, 397 M parameters)" if args.unfreeze else "frozen"),
                        "global_batch": world * args.batch,
-                       "precision": ("fp32 tensors, every product = 3 bf16 MFMA products on operands split hi+lo on the fly, fp32 accumulate"
+                       "precision": (("fp32 tensors, every product = 3 bf16 MFMA products on operands split hi+lo on the fly, fp32 accumulate"
+                                      if args.precision == "bf16x3" else
+                                      "AMP line (the reference's --use_amp, bf16 autocast): fp32 tensors, operands rounded to bf16 on the fly, 1 bf16 MFMA "
+                                      "product per multiply in the encoders' Linear layers and in every backward product, fp32 accumulate; head "
+                                      "forward stays 3 products; no 1e-3 parity claim")
                                      if args.unfreeze else
                                      "bf16x3: operands split into bf16 hi+lo planes, 3 bf16 MFMA products per multiply, fp32 accumulate"
                                      if args.precision == "bf16x3" else "bf16: 1 bf16 MFMA product per multiply, fp32 accumulate (fast mode, no 1e-3 parity claim)"),

@@ -257,6 +257,10 @@ int ser_stack_ln_param_bwd(const void* grad_table, const float* x0, const float*
  * per multiply (hi*hi + lo*hi + hi*lo, fp32-equivalent; default) or 1 (operands rounded to bf16, fp32 accumulation -
  * what mixed-precision training does for every matmul).  Forward products always use 3.  Process-wide setting. */
 int ser_set_head_backward_products(int n);
+/* MFMA products per multiply of ser_linear_fwd / ser_linear_fwd_group: 3 (default, fp32-equivalent) or 1 (bf16 operands, fp32
+ * accumulation: the arithmetic of the reference's --use_amp bf16 autocast, ref src/train.py:151). */
+int ser_set_linear_forward_products(int n);
+int ser_get_linear_forward_products(void);
 int ser_get_head_backward_products(void);
 /* relu_mask (may be NULL): the ReLU OUTPUT of the layer that produced x; when given, dx is multiplied by
  * relu'(mask), i.e. the activation backward is fused into the dgrad epilogue. */

@@ -138,6 +138,22 @@ class fork:
                 t.record_stream(self.side)
 
 
+L._sig("ser_set_linear_forward_products", L.i32, L.i32)
+L._sig("ser_get_linear_forward_products", L.i32)
+
+
+@contextlib.contextmanager
+def linear_forward_products(n):
+    """Token-level forward Linear products inside the scope use `n` MFMA products per multiply (3: fp32-equivalent, 1: bf16
+    operands - the reference's --use_amp arithmetic).  The fine-tuning encoders select 1 in the `bf16` precision mode."""
+    prev = L.lib.ser_get_linear_forward_products()
+    L.check(L.lib.ser_set_linear_forward_products(int(n)), "ser_set_linear_forward_products")
+    try:
+        yield
+    finally:
+        L.lib.ser_set_linear_forward_products(prev)
+
+
 # `loss.backward()` without arguments seeds the graph with ones: the fused loss kernel has already written d(loss)/d(inputs)
 # for that seed, so scaling its four gradient tensors by the upstream value (four launches, plus autograd's fill of the
 # seed) is only needed when a caller backpropagates something else through the loss.  The steppers, which always call

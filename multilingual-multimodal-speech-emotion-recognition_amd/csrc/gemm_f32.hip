@@ -874,6 +874,17 @@ extern "C" int ser_set_head_backward_products(int n) {
   return SER_OK;
 }
 extern "C" int ser_get_head_backward_products(void) { return g_head_bwd_products; }
+// MFMA products per multiply of ser_linear_fwd / ser_linear_fwd_group (token-level forward products).  3 = default (fp32-
+// equivalent; the 1e-3 logit budget is a forward bound).  1 = bf16 operands, fp32 accumulation: what the reference's
+// --use_amp (bf16 autocast, ref src/train.py:151) computes; the fine-tuning form of the encoders selects it around ITS
+// Linear layers in the `bf16` precision mode (models/_finetune.py), the trainable head keeps 3.
+static int g_linear_fwd_products = 3;
+extern "C" int ser_set_linear_forward_products(int n) {
+  SER_REQUIRE(n == 1 || n == 3, "linear forward products must be 1 or 3");
+  g_linear_fwd_products = n;
+  return SER_OK;
+}
+extern "C" int ser_get_linear_forward_products(void) { return g_linear_fwd_products; }
 extern "C" int ser_debug_set_head_x3(int v) { g_use_x3 = v; return 0; }
 
 static void launch_6464(const SerGemmF32Args& g, dim3 grid, hipStream_t st) {
@@ -1017,7 +1028,12 @@ extern "C" int ser_linear_fwd(const float* x, const float* W, const float* bias,
     SER_LAUNCH_CHECK();
     return SER_OK;
   }
-  return ser_gemm_f32(x, K, 1, W, 1, K, M, N, K, bias, act, residual, ldr, y, N, 0, stream);
+  SerGemmF32Args g;
+  g.a = x; g.b = W; g.c = y; g.M = M; g.N = N; g.K = K;
+  g.sam = K; g.sak = 1; g.sbk = 1; g.sbn = K; g.ldc = N;
+  g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr; g.accumulate = 0;
+  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0; g.products = g_linear_fwd_products;
+  return ser_launch_gemm_f32(g, st);
 }
 
 // y = act(LN(LN(x; g1,b1); g2,b2) W^T + bias) with x1, u and the LayerNorm statistics written out (M <= 16, K <= 512)
@@ -1099,11 +1115,11 @@ extern "C" int ser_linear_fwd_group(const void* const* ptrs, const int* dims, in
     SerGemmF32Args g;
     g.a = x; g.b = W; g.c = y; g.M = M; g.N = N; g.K = K; g.sam = K; g.sak = 1; g.sbk = 1; g.sbn = K; g.ldc = N;
     g.bias = b; g.act = act; g.residual = r; g.ldr = ldr; g.accumulate = 0; g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr;
-    g.vec_a = vec_ok(x, 1, K, K) ? 1 : 0; g.vec_b = vec_ok(W, 1, K, K) ? 1 : 0; g.products = 3;
+    g.vec_a = vec_ok(x, 1, K, K) ? 1 : 0; g.vec_b = vec_ok(W, 1, K, K) ? 1 : 0; g.products = g_linear_fwd_products;
     if (x3_multi_ok(g)) grp[ng++] = g;
     else SER_TRY(ser_linear_fwd(x, W, b, act, r, ldr, y, M, N, K, stream));
   }
-  return ng ? launch_x3_multi<1>(grp, ng, 3, (hipStream_t)stream) : SER_OK;
+  return ng ? launch_x3_multi<1>(grp, ng, g_linear_fwd_products, (hipStream_t)stream) : SER_OK;
 }
 
 // dx_i[M,K] (+)= dy_i[M,N] W_i[N,K].  ptrs: 3 per problem {dy, W, dx}; dims: 4 per problem {M, N, K, accumulate}.

@@ -153,11 +153,15 @@ class AudioEncoder(nn.Module):
                 if getattr(self, "_noise", None) is None:
                     self._noise = Noise(self.encoder.config, 0, seed=getattr(self, "noise_seed", 0))
                 noise = self._noise
-            if self.freeze_base:
-                with torch.no_grad():
+            # `bf16` precision mode (train.py --use_amp / --precision bf16): one MFMA product per multiply in the encoder's Linear
+            # layers, as bf16 autocast computes them; `bf16x3`: three
+            with O.linear_forward_products(1 if self.precision == "bf16" else 3):
+                if self.freeze_base:
+                    with torch.no_grad():
+                        seq = wav2vec2_forward(self.encoder, wave, noise)
+                else:
                     seq = wav2vec2_forward(self.encoder, wave, noise)
-                return adapter_apply(self, seq)
-            return adapter_apply(self, wav2vec2_forward(self.encoder, wave, noise))
+            return adapter_apply(self, seq)
         with torch.no_grad():
             seq = self.engine().forward(wave)
         return adapter_apply(self, seq)

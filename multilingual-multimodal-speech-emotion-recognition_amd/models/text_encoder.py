@@ -74,11 +74,13 @@ class TextEncoder(nn.Module):
                 if getattr(self, "_noise", None) is None:
                     self._noise = Noise(self.encoder.config, 1, seed=getattr(self, "noise_seed", 0))
                 noise = self._noise
-            if self.freeze_base:
-                with torch.no_grad():
+            from .. import _ops as O
+            with O.linear_forward_products(1 if self.precision == "bf16" else 3):      # see AudioEncoder.encode
+                if self.freeze_base:
+                    with torch.no_grad():
+                        seq = xlmr_forward(self.encoder, ids, mask, noise)
+                else:
                     seq = xlmr_forward(self.encoder, ids, mask, noise)
-            else:
-                seq = xlmr_forward(self.encoder, ids, mask, noise)
             return adapter_apply(self, seq), mask.to(seq.dtype)
         with torch.no_grad():
             seq = self.engine().forward(ids, mask)

@@ -51,7 +51,10 @@ def build_parser():
     p.add_argument('--batch_size', type=int, default=4)
     p.add_argument('--lr', type=float, default=1e-4)
     p.add_argument('--warmup_ratio', type=float, default=0.1)
-    p.add_argument('--use_amp', action='store_true', help='accepted for compatibility: the encoders already run bf16 MFMA')
+    p.add_argument('--use_amp', action='store_true',
+                   help="the reference's mixed-precision switch (ref train.py:34,88,151: bf16 autocast): selects --precision bf16, i.e. one bf16 "
+                        "MFMA product per multiply with fp32 accumulation in the encoders (frozen or fine-tuned) and in the head's backward "
+                        "products; the head's forward stays fp32-equivalent.  No loss scaling is needed for bf16 (GradScaler is a no-op there)")
     p.add_argument('--augment', action='store_true')
     p.add_argument('--proto_weight', type=float, default=0.05)
     p.add_argument('--save_dir', type=str, default='checkpoints')
@@ -284,6 +287,8 @@ def run(args, engine, sampler, train_loader, val_loader, rank=0, world=1, log=pr
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.use_amp:
+        args.precision = 'bf16'
     if not torch.cuda.is_available():
         raise SystemExit("the HIP hot path needs an MI355X; there is no CPU fallback")
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))

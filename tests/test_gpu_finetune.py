@@ -87,7 +87,10 @@ def test_text_encoder_gradients_match_the_reference():
     assert float(named["encoder.embeddings.position_embeddings.weight"].grad[pad].abs().max()) == 0.0
 
 
-def test_full_fine_tune_step_matches_the_oracle():
+@pytest.mark.parametrize("width", ["small", "base"])
+def test_full_fine_tune_step_matches_the_oracle(width):
+    """width "base": the Base-width layer shapes of BASELINE config 3 (768-d, 12 heads, FFN 3072, the 512-channel conv front end,
+    128-tap 16-group positional conv) at 2 layers per encoder, so the oracle's autograd step stays a matter of seconds."""
     import __graft_entry__ as ge
     from transformers import Wav2Vec2Config, XLMRobertaConfig
     import ser_amd  # noqa: F401
@@ -95,13 +98,21 @@ def test_full_fine_tune_step_matches_the_oracle():
     from ser_amd.system import SERSystem, TrainStepper
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
-                        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
-    xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
-                          max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
-    ae = AudioEncoder(hf_config=wc, adapter_dim=32, freeze_base=False, use_quality_gates=False, use_audio_conditioning=False)
-    te = TextEncoder(hf_config=xc, adapter_dim=32, freeze_base=False)
-    sysm = SERSystem(ae, te, num_labels=4, shared_dim=64, num_heads=2, proj_dim=64, num_layers=3, base_dim=64).to(dev)
+    if width == "base":
+        wc = Wav2Vec2Config(num_hidden_layers=2)
+        xc = XLMRobertaConfig(vocab_size=1000, num_hidden_layers=2, max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5,
+                              pad_token_id=1, bos_token_id=0, eos_token_id=2)
+        ae = AudioEncoder(hf_config=wc, freeze_base=False, use_quality_gates=False, use_audio_conditioning=False)
+        te = TextEncoder(hf_config=xc, freeze_base=False)
+        sysm = SERSystem(ae, te, num_labels=4, num_layers=3).to(dev)
+    else:
+        wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
+                            num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4)
+        xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                              max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+        ae = AudioEncoder(hf_config=wc, adapter_dim=32, freeze_base=False, use_quality_gates=False, use_audio_conditioning=False)
+        te = TextEncoder(hf_config=xc, adapter_dim=32, freeze_base=False)
+        sysm = SERSystem(ae, te, num_labels=4, shared_dim=64, num_heads=2, proj_dim=64, num_layers=3, base_dim=64).to(dev)
     sysm.train()
     sysm.train_dropout = False
     g = torch.Generator().manual_seed(5)
@@ -117,7 +128,7 @@ def test_full_fine_tune_step_matches_the_oracle():
     sds = {k: {n: v.detach().cpu().clone() for n, v in getattr(sysm, k).state_dict().items()} for k in sysm.CKPT_KEYS}
     a_cfg, t_cfg = ge.oracle_cfgs(wc, xc)
     leaf = {k: {n: v.clone().requires_grad_(v.dtype.is_floating_point) for n, v in sd.items()} for k, sd in sds.items()}
-    out = O.full_forward(leaf, list(wave), ids, mask, a_cfg, t_cfg, num_layers=3, heads=2, use_openmax=False, training=True)
+    out = O.full_forward(leaf, list(wave), ids, mask, a_cfg, t_cfg, num_layers=3, heads=8 if width == "base" else 2, use_openmax=False, training=True)
     ref_loss = O.train_loss(out["logits"], out["unc"], out["fused"], leaf["prototypes"]["prototypes"], labels, 4)
     ref_loss.backward()
 
