@@ -62,6 +62,10 @@ int ser_stream_destroy(void* stream);
 
 /* x[n] fp32 -> hi[n], lo[n] bf16 planes (lo may be NULL; interleaved when lo == hi + 32, then n % 32 == 0). */
 int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long long n, void* stream);
+/* x [R, C] fp32 (row stride ldx) -> split planes of x^T: C rows of Rp >= R values, zero beyond R (Rp % 32 == 0); interleaved
+ * when lo == hi + 32, the hi plane alone when lo == NULL.  Gives the K-contiguous NT GEMM the transposed operands of a Linear
+ * layer's backward products (dx = dy W, dW = dy^T x) on the fine-tuning path (BASELINE config 3). */
+int ser_split_bf16_t(const float* x, int R, int C, long long ldx, uint16_t* hi, uint16_t* lo, int Rp, void* stream);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, split-bf16 operands, fp32 accumulate.
  * Replaces every torch.nn.Linear / Conv1d-as-GEMM inside the frozen encoders
@@ -292,6 +296,10 @@ int ser_layernorm2_bwd(const float* du, const float* dres, const float* x, const
                        const float* g1, const float* g2, int rows, int D, float* dx, float* dg1, float* db1,
                        float* dg2, float* db2, int accumulate, void* stream);
 int ser_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream);
+/* the same for tall x (thousands of rows): 32 row chunks in parallel, then their sum, in a fixed order; ws from
+ * ser_colsum_tall_workspace_bytes(N).  The bias gradient of the fine-tuning encoders' Linear layers. */
+size_t ser_colsum_tall_workspace_bytes(int N);
+int ser_colsum_tall(const float* x, int M, int N, int ld, float* out, void* ws, void* stream);
 int ser_act_fwd(const float* x, int act, long long n, float* y, void* stream);
 int ser_act_bwd(const float* dy, const float* y, int act, long long n, float* dx, void* stream);
 /* activation followed by dropout in one pass, and its backward (see ser_dropout for the generator arguments) */

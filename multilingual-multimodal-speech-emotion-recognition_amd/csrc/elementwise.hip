@@ -73,6 +73,46 @@ extern "C" int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long l
   return ser_launch_split(x, hi, lo, n, (hipStream_t)stream);
 }
 
+// x [R, C] fp32 (row stride ldx) -> split planes of x^T: C rows of Rp >= R values (zero beyond R), Rp % 32 == 0.
+// lo == hi + 32 elements: interleaved layout (row c occupies 2 Rp bf16, every 32 hi values followed by their 32 lo values);
+// lo == nullptr: the hi plane alone, rows of Rp values.  A 32 x 32 tile goes through LDS, so reads run along C and writes
+// along R.  Feeds the K-contiguous NT GEMM with the transposed operands of a Linear layer's backward products
+// (dx = dy W: W^T; dW = dy^T x: dy^T and x^T), so that the fine-tuning path runs on the encoder tile kernels.
+__global__ __launch_bounds__(256) void split_t_kernel(const float* __restrict__ x, int R, int C, long long ldx, bf16_t* __restrict__ hi,
+                                                      bf16_t* __restrict__ lo, int Rp) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < R && c < C) ? x[(long long)r * ldx + c] : 0.f;
+  }
+  __syncthreads();
+  const bool il = lo != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i;
+    if (c >= C) continue;
+    bf16_t h, l;
+    split_bf16(tile[tx][ty + 8 * i], h, l);
+    if (il) {
+      const long long o = (long long)c * 2 * Rp + 2 * r0 + tx;      // il_off(r0 + tx) with r0 % 32 == 0
+      hi[o] = h;
+      hi[o + SER_IL_GROUP] = l;
+    } else {
+      hi[(long long)c * Rp + r0 + tx] = h;
+    }
+  }
+}
+extern "C" int ser_split_bf16_t(const float* x, int R, int C, long long ldx, uint16_t* hi, uint16_t* lo, int Rp, void* stream) {
+  SER_REQUIRE(x && hi && R > 0 && C > 0 && Rp >= R && Rp % SER_IL_GROUP == 0, "split_bf16_t: bad arguments (R=%d C=%d Rp=%d)", R, C, Rp);
+  SER_REQUIRE(lo == nullptr || ser_is_il(hi, lo), "split_bf16_t: both planes are written only in the interleaved layout (lo == hi + 32)");
+  hipLaunchKernelGGL(split_t_kernel, dim3(Rp / 32, ceil_div(C, 32)), dim3(256), 0, (hipStream_t)stream, x, R, C, ldx, hi, lo, Rp);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // LayerNorm over the last dim: one wave per row, row kept in registers (D <= 1024, D % 4 == 0)
 // ------------------------------------------------------------------------------------------

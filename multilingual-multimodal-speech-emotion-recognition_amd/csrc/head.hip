@@ -345,6 +345,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   }
 }
 
+// the same over many rows in two deterministic stages: part[c][n] = sum of row chunk c (grid.y chunks), then colsum_kernel over
+// the chunk sums (a fixed summation order: no atomics)
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ x, int M, int N, int ld, float* __restrict__ part) {
+  __shared__ float sh[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  const int per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(M, r0 + per);
+  float a = 0.f;
+  if (col < N)
+    for (int r = r0 + rg; r < r1; r += 4) a += x[(long long)r * ld + col];
+  sh[rg][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (rg == 0 && col < N) {
+    const int c = threadIdx.x;
+    part[(long long)blockIdx.y * N + col] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  }
+}
+
 // dx = dy * act'(y) given the activation OUTPUT y
 // with `drop`: y was produced as dropout(act(x)); dx = dy * mask / (1 - p) * act'(y)  (for ReLU, y > 0 <=> active and kept)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, int act, long long n,
@@ -1229,6 +1248,18 @@ extern "C" int ser_layernorm2_bwd(const float* du, const float* dres, const floa
 extern "C" int ser_colsum(const float* x, int M, int N, int ld, float* out, int accumulate, void* stream) {
   if (M <= 0 || N <= 0) return SER_OK;
   hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, x, M, N, ld, out, accumulate);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+// out[n] = sum_m x[m*ld + n] for tall x: SER_COLSUM_CHUNKS row chunks in parallel, then their sum; ws: SER_COLSUM_CHUNKS * N floats
+#define SER_COLSUM_CHUNKS 32
+extern "C" size_t ser_colsum_tall_workspace_bytes(int N) { return (size_t)SER_COLSUM_CHUNKS * (size_t)(N > 0 ? N : 0) * sizeof(float); }
+extern "C" int ser_colsum_tall(const float* x, int M, int N, int ld, float* out, void* ws, void* stream) {
+  if (M <= 0 || N <= 0) return SER_OK;
+  SER_REQUIRE(ws, "colsum_tall: no workspace");
+  hipLaunchKernelGGL(colsum_part_kernel, dim3(ceil_div(N, 64), SER_COLSUM_CHUNKS), dim3(256), 0, (hipStream_t)stream, x, M, N, ld, (float*)ws);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, (hipStream_t)stream, (const float*)ws, SER_COLSUM_CHUNKS, N, N, out, 0);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

@@ -52,24 +52,83 @@ def _wgrad_now(dy, x, dW, db):
         O._DEFER["active"] = prev
 
 
+_sig("ser_colsum_tall_workspace_bytes", L.sz, L.i32)
+_sig("ser_colsum_tall", L.i32, L.vp, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp)
+
+
+def _planes(x, three):
+    """fp32 [R, C] (C % 64 == 0) -> kernel operand of the encoder NT GEMM: interleaved hi/lo planes, or the hi plane alone."""
+    if three:
+        t = L.split_bf16_il(x)
+        return t, t.data_ptr(), t.data_ptr() + 2 * L.IL_GROUP
+    hi, _ = L.split_bf16(x, False)
+    return hi, hi.data_ptr(), None
+
+
+def _planes_t(x, three):
+    """fp32 [R, C] -> operand planes of x^T [C, Rp] (R zero-padded to a multiple of 64): (keep-alive, hi, lo, Rp)."""
+    t, Rp = L.split_bf16_t(x, three)
+    return t, t.data_ptr(), (t.data_ptr() + 2 * L.IL_GROUP) if three else None, Rp
+
+
+def _nt(a, lda, w, ldw, M, N, K, out, bias=None):
+    """out[M,N] fp32 = A[M,K] . W[N,K]^T (+ bias) on the encoder tile kernel (csrc/gemm_bf16.hip); a / w = (hi, lo) pointers."""
+    L.check(L.lib.ser_gemm_bf16_nt(a[0], a[1], int(lda), w[0], w[1], int(ldw), int(M), int(N), int(K), L.ptr(bias), L.ACT_NONE, None, 0,
+                                   out.data_ptr(), None, None, int(N), L.stream_ptr()), "ser_gemm_bf16_nt")
+
+
+def _tile_ok(M, N, K):
+    return M >= 64 and N % 64 == 0 and K % 64 == 0
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b on contiguous fp32 [M, K]: the head's Linear kernels (forward / dgrad / wgrad with the bias gradient
-    folded in)."""
+    """y = x W^T + b on contiguous fp32 [M, K].
+
+    Encoder-sized layers (M >= 64, N and K multiples of 64) run all three products on the MFMA tile kernel of the frozen
+    encoders (csrc/gemm_bf16.hip, K-contiguous NT form): the operands are split into bf16 planes by one elementwise pass each
+    - transposed where the product needs it (dx = dy W reads W^T; dW = dy^T x reads dy^T and x^T, the token axis zero-padded
+    to a multiple of 64) - which costs a few MB of traffic per layer against a 5x faster product than the head's 64 x 64
+    on-the-fly-split kernel.  Products per multiply: forward `ser_get_linear_forward_products` (3, or 1 under --use_amp),
+    backward `ser_get_head_backward_products`.  Smaller layers keep the head's kernels."""
 
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.has_b = b is not None
-        return O.linear_fwd(x, W, b)
+        M, K = x.shape
+        N = W.shape[0]
+        ctx.tile = _tile_ok(M, N, K)
+        if not ctx.tile:
+            return O.linear_fwd(x, W, b)
+        three = L.lib.ser_get_linear_forward_products() == 3
+        xs, ws = _planes(x, three), _planes(W, three)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _nt(xs[1:], K, ws[1:], K, M, N, K, y, b)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = O.linear_dgrad(dy, W) if ctx.needs_input_grad[0] else None
+        M, K = x.shape
+        N = W.shape[0]
         dW = torch.empty_like(W)
-        db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_b else None
-        _wgrad_now(dy, x, dW, db)
+        db = torch.empty(N, dtype=torch.float32, device=W.device) if ctx.has_b else None
+        if not ctx.tile:
+            dx = O.linear_dgrad(dy, W) if ctx.needs_input_grad[0] else None
+            _wgrad_now(dy, x, dW, db)
+            return dx, dW, db
+        three = L.lib.ser_get_head_backward_products() == 3
+        dx = None
+        if ctx.needs_input_grad[0]:                              # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
+            dys, wt = _planes(dy, three), _planes_t(W, three)
+            dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+            _nt(dys[1:], N, wt[1:3], wt[3], M, K, N, dx)
+        dyt, xt = _planes_t(dy, three), _planes_t(x, three)       # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
+        _nt(dyt[1:3], dyt[3], xt[1:3], xt[3], N, K, dyt[3], dW)
+        if db is not None:
+            ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(N)), dtype=torch.uint8, device=dy.device)
+            L.check(L.lib.ser_colsum_tall(L.ptr(dy), M, N, N, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
         return dx, dW, db
 
 
@@ -385,9 +444,12 @@ def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask, noise=No
     """Post-LN block (hf wav2vec2 :591-608 / xlm_roberta :421-463), h [B*S, H].  With `noise`: attention-probability,
     hidden (after the attention output and after the FFN output) and activation dropout, as the HF modules place them."""
     g = lambda n: p[prefix + n]
-    q = linear(h, g(names["q"] + ".weight"), g(names["q"] + ".bias"))
-    k = linear(h, g(names["k"] + ".weight"), g(names["k"] + ".bias"))
-    v = linear(h, g(names["v"] + ".weight"), g(names["v"] + ".bias"))
+    # q, k, v as ONE product over the concatenated weights (a copy of 3 H^2 values per layer and step; autograd slices the
+    # weight gradient back): one split of h, one launch, N = 3 H
+    Hd = h.shape[1]
+    qkv = linear(h, torch.cat([g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight")], dim=0),
+                 torch.cat([g(names["q"] + ".bias"), g(names["k"] + ".bias"), g(names["v"] + ".bias")], dim=0))
+    q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
     adrop = O.dropout_ctx(noise.p_attn) if noise is not None else None
     ctx = _Attention.apply(q, k, v, key_mask, B, S, heads, adrop, noise.site(layer, 0) if noise is not None else 0)
     a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"))
