@@ -136,38 +136,71 @@ def cpu_baseline_and_parity(sample, sysm, wc, xc, args):
 
 def inference_leg(sysm, batches, steps=12):
     """Forward-only throughput of the same path (ref src/eval.py:160-206: encoders, head, OpenMax logits, softmax / arg-max /
-    energy) on ONE hipGraph over all the resident clips at once (4 x batch clips: the encoder GEMMs see the same rows as a
-    grouped training pass).  Extra key of the bench line; never part of `value`."""
+    energy) over all the resident clips at once (4 x batch clips per pass: the encoder GEMMs see the same rows as a grouped
+    training pass), as two hipGraphs per pass - frozen encoders | adapters + head + consumers - with the encoders of pass i+1 on
+    a second stream beside the head of pass i (two output slots).  Extra key of the bench line; never part of `value`."""
     from ser_amd import _ops as O
     was_training = sysm.training
     sysm.eval()
     wave, ids, mask = (torch.cat([b[i] for b in batches]).clone() for i in range(3))
     n = wave.shape[0]
+    cur, es = torch.cuda.current_stream(), torch.cuda.Stream()
 
-    def fwd():
-        return O.eval_consumers(sysm(wave, ids, mask, use_openmax=True), 1.0)
+    def head(a_enc, t_enc, gf):
+        a_seq, t_seq = sysm._adapters(a_enc, t_enc)
+        if gf:
+            a_seq = sysm.audio_encoder.fuse_gate_features(a_seq, *gf)
+        fused = sysm.head(a_seq, sysm._ones_mask(a_seq), t_seq, mask.to(torch.float32))
+        return O.eval_consumers(sysm.classifier(fused, use_openmax=True), 1.0)
+
+    def encode():
+        if sysm.gates_on():
+            a, t, q, c = sysm.encode_frozen_gated(wave, ids, mask)
+            return a, t, (q, c)
+        a, t = sysm.encode_frozen(wave, ids, mask)
+        return a, t, None
     with torch.no_grad():
+        sysm.prepare()
         side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(2):
-                fwd()
-        torch.cuda.current_stream().wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            probs, pred, energy = fwd()
-        for _ in range(2):
-            g.replay()
+                a, t, gf = encode()
+                head(a, t, gf)
+        cur.wait_stream(side)
+        slots, g_enc, g_head, outs = [], [], [], []
+        for k in range(2):
+            ge = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ge):
+                a, t, gf = encode()
+            gh = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gh):
+                outs.append(head(a, t, gf))
+            slots.append((a, t, gf)); g_enc.append(ge); g_head.append(gh)
+        enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+        head_done = [torch.cuda.Event(), torch.cuda.Event()]
+
+        def run(passes):
+            for i in range(passes):
+                k = i & 1
+                es.wait_event(head_done[k])              # the head of pass i-2 has consumed this slot
+                with torch.cuda.stream(es):
+                    g_enc[k].replay()
+                    enc_done[k].record(es)
+                cur.wait_event(enc_done[k])
+                g_head[k].replay()
+                head_done[k].record(cur)
+        run(4)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for j in range(steps):
-            g.replay()
+        run(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     sysm.train(was_training)
-    ok = bool(torch.isfinite(probs).all())
-    return dict(clips_per_pass=n, ms_per_pass=round(dt / steps * 1e3, 3), utt_per_s=round(n * steps / dt, 1), finite=ok,
-                what="forward only: encoders + head + OpenMax + softmax / arg-max / energy, one hipGraph, inputs resident")
+    probs = outs[(steps - 1) & 1][0]
+    return dict(clips_per_pass=n, ms_per_pass=round(dt / steps * 1e3, 3), utt_per_s=round(n * steps / dt, 1), finite=bool(torch.isfinite(probs).all()),
+                what="forward only: encoders | adapters + head + OpenMax + softmax / arg-max / energy as two hipGraphs per pass, the encoders "
+                     "of the next pass on a second stream beside the head of this one; inputs resident")
 
 
 def spawn_ranks(n, argv):
