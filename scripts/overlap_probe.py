@@ -14,7 +14,8 @@ sysm.train()
 opt = sysm.make_optimizer(1e-4)
 st = PipelinedStepper(sysm, opt)
 b = [t.to(dev) for t in bench.synth_batch(16, 4.0, 32, xc.vocab_size, 4, 1)]
-st.feed(*b)
+for _ in range(st.prime):
+    st.feed(*b)
 for _ in range(3):
     st.step(*b)
 torch.cuda.synchronize()
