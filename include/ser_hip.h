@@ -470,6 +470,7 @@ int ser_get_gemm_occupancy_pct(void);
 /* experiment / test knobs (scripts/, tests/): force a tile configuration, LDS pipeline depths, extra dynamic LDS, a
  * persistent grid cap, kernel variants; stand-alone probes of single kernels */
 int ser_debug_set_gemm_bm(int cfg);
+int ser_debug_set_gemm_group_m(int m_tiles_per_super_tile);
 int ser_debug_set_gemm_stages(int s128, int s64x128, int s64, int s128x64);
 int ser_debug_set_gemm_stages_tall(int s96, int s160, int s192);
 int ser_debug_set_gemm_lds_pad(int bytes);

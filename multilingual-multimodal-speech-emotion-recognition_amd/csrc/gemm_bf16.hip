@@ -156,7 +156,7 @@ SER_DEVFN void gemm_tile(const SerGemmArgs& g, const int bid_in, const int bz, c
     const int nt = tiles_m * tiles_n, bid = bid_in;
     const int q = nt >> 3, r = nt & 7, xcd = bid & 7, local = bid >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    constexpr int GROUP_M = 4;
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 4;
     const int per_group = GROUP_M * tiles_n;
     const int first_m = (t / per_group) * GROUP_M;
     const int gsz = min(GROUP_M, tiles_m - first_m);
@@ -666,6 +666,8 @@ static int gemm_check(const SerGemmArgs& g) {
 // its rows plus a constant (W panel, prologue, epilogue).  g_gemm_force_bm overrides (experiments / tests).
 static int g_gemm_force_bm = 0;
 extern "C" int ser_debug_set_gemm_bm(int bm) { g_gemm_force_bm = bm; return 0; }
+static int g_gemm_group_m = 0;       // 0 = rule below; experiments: m-tiles per super-tile of the tile order
+extern "C" int ser_debug_set_gemm_group_m(int v) { g_gemm_group_m = v; return 0; }
 
 template <int BM>
 static int slots_per_cu() {
@@ -765,7 +767,13 @@ static int launch_narrow(int cfg, const SerGemmArgs* small, const SerGemmArgs& b
   return SER_E_ARG;
 }
 
-static int launch_bn128(const SerGemmArgs* small, const SerGemmArgs& big, hipStream_t st) {
+static int launch_bn128(const SerGemmArgs* small_in, const SerGemmArgs& big_in, hipStream_t st) {
+  SerGemmArgs big = big_in, small_copy;
+  const SerGemmArgs* small = small_in;
+  if (g_gemm_group_m > 0) {
+    big.group_m = g_gemm_group_m;
+    if (small_in) { small_copy = *small_in; small_copy.group_m = g_gemm_group_m; small = &small_copy; }
+  }
   const long long rows_a = small ? (long long)small->M * small->nb1 * small->nb2 : 0;
   const int cfg = big.cfg ? big.cfg : pick_bm(rows_a, big.M, big.N, big.K, (long long)big.nb1 * big.nb2, gemm_mode(big));
   if (cfg >= SER_GEMM_CFG_NARROW && cfg < SER_GEMM_CFG_NARROW + 1000) return launch_narrow(cfg, small, big, st);

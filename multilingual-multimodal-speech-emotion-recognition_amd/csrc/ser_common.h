@@ -195,6 +195,7 @@ struct SerGemmArgs {
   int ksplit;
   long long slab_stride;
   int cfg;                     // tile configuration id (SER_GEMM_CFG_*), 0 = let the launcher choose
+  int group_m;                 // tile order: m-tiles per super-tile (0 = launcher default); pure speed, any value gives the same result
 };
 // tile configurations: 64..192 = rows of a 256-thread BM x 128 tile; the 512-thread tiles:
 enum { SER_GEMM_CFG_NARROW = 7000 /* + rows: BM x 64 tiles */, SER_GEMM_CFG_SINGLE = 3000 /* + rows: single LDS buffer, three workgroups per CU */, SER_GEMM_CFG_WIDE = 1000, SER_GEMM_CFG_128x256 = 1128, SER_GEMM_CFG_192x256 = 1192, SER_GEMM_CFG_256x256 = 1256, SER_GEMM_CFG_256x128 = 2256,

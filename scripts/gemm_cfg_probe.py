@@ -10,6 +10,8 @@ import ser_amd  # noqa: F401
 from ser_amd import _lib as L
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if os.environ.get("SER_GEMM_GROUP_M"):
+    L.lib.ser_debug_set_gemm_group_m(int(os.environ["SER_GEMM_GROUP_M"]))
 CFGS = [int(v) for v in sys.argv[2:]] or [128, 192, 3128, 1256, 6256, 8256]
 rows = G * (16 * 199 + 16 * 32)
 SHAPES = [("qkv", rows, 2304, 768), ("oproj", rows, 768, 768), ("ffn1", rows, 3072, 768), ("ffn2", rows, 768, 3072),
