@@ -843,22 +843,42 @@ class PipelinedStepper:
     def profile_encoder_passes(self, n=3):
         """`n` encoder passes over slot 0's staged group issued EAGERLY on the encoder stream - the same launches the
         slot's graph replays, but outside a graph, so that per-launch HIP events (ser_prof_gemm_start / _stop) can
-        bracket them - each beside `group` head-graph replays on the current stream, as in the timed schedule.
-        Idempotent for training state: no optimizer step, gradients reset afterwards."""
+        bracket them - each beside `group` head-graph replays on the current stream, as in the timed schedule, back to back
+        without a host synchronisation in between (the chip's clock management reacts to the load of the last milliseconds: an
+        idle gap between passes would let it recover and flatter the kernels).  Probe waves started with each pass report the
+        shader clock they saw (`clock_ghz_per_pass`, `clock_ghz_under_load` = their median).  Idempotent for training state: no optimizer step,
+        gradients reset afterwards."""
+        from . import _lib as L
+        import ctypes as C
         cur, es = torch.cuda.current_stream(), self.enc_stream
+        probe_stream = torch.cuda.Stream()
+        probe = torch.zeros(n, 8, 2, dtype=torch.int64, device=self.enc_cur[0].device)
+        fn = L.lib.ser_debug_clock_probe
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         torch.cuda.synchronize()
-        for _ in range(n):
+        keep = []
+        for i in range(n):
             es.wait_stream(cur)
             with torch.cuda.stream(es):
+                started = torch.cuda.Event()
+                started.record(es)
                 outs = self._encode_slot(0)
+            probe_stream.wait_event(started)             # the probe starts with this pass and runs beside its first ~6 ms
+            with torch.cuda.stream(probe_stream):        # dependent FMAs on 8 waves (one per XCD by round-robin placement)
+                L.check(fn(probe[i].data_ptr(), 8, 400000, probe_stream.cuda_stream), "ser_debug_clock_probe")
             for _ in range(self.group):
                 self.g_head.replay()
                 if self.g_head_b is not None:
                     self.g_head_b.replay()
             cur.wait_stream(es)
+            keep.append(outs)
             for x in outs:
                 x.record_stream(cur)
         torch.cuda.synchronize()
+        v = probe.cpu().double()
+        ghz = (v[..., 0] / v[..., 1].clamp(min=1) * 0.1).median(dim=1).values            # per pass
+        self.clock_ghz_per_pass = [round(float(g), 3) for g in ghz]
+        self.clock_ghz_under_load = float(ghz.median())
         self._reset_grads_after_idle_replays()
 
     def _reset_grads_after_idle_replays(self):
