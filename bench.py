@@ -337,8 +337,10 @@ def main():
             m.encoder_train_noise, m.noise_seed = True, rank
     opt = sysm.make_optimizer(lr=1e-4)
     reducer = GradReducer(sysm) if world > 1 else None
-    # LayerDrop changes which kernels run from step to step (a host decision, as in HF): the fine-tune configuration steps eagerly
-    use_graph = not args.no_graph and not args.unfreeze
+    # the fine-tune configuration is captured too: LayerDrop / SpecAugment decisions are drawn on the host before each replay and
+    # travel as device words (models/_finetune.py Noise.stage; a dropped layer is computed and discarded by a select, the optimizer
+    # leaves its parameters untouched through the same word)
+    use_graph = not args.no_graph
     split = None if "SER_SPLIT_BACKWARD" not in os.environ else os.environ["SER_SPLIT_BACKWARD"] == "1"
     stepper = TrainStepper(sysm, opt, None, reducer, use_graph=use_graph, split_backward=split)
     # four distinct device-resident batches, visited round-robin: nothing can be reused from one step to the next

@@ -438,6 +438,12 @@ int ser_gemm_tile_hint_mode(long long rows_total, int N, int K, int three_produc
  * 16 segments; ptrs = host array {p, g, m, v} per segment, n / lr_mult / weight_decay = host arrays per segment */
 int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay, int nseg,
                     const float* hyper, float beta1, float beta2, float eps, void* stream);
+/* ... with an optional device word per segment (gates = host array of device `const int*`, null entries = always update):
+ * a segment whose word is non-zero when the kernel runs takes no update, moments included - what torch.optim.AdamW does for a
+ * parameter without a gradient.  The graph-captured fine-tuning step computes LayerDrop-skipped layers (hf
+ * modeling_wav2vec2.py:700-703) and discards them by a select, so their parameters need this to stay untouched. */
+int ser_adamw_multi_gated(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay,
+                          const void* const* gates, int nseg, const float* hyper, float beta1, float beta2, float eps, void* stream);
 
 /* ---- data feed on the device (src/data/preprocess.py:50-73) ---------------------------
  * ser_resample: torchaudio.functional.resample (windowed sinc, Hann window, lowpass_filter_width 6, rolloff 0.99 by

@@ -228,6 +228,7 @@ _sig("ser_resample", i32, vp, i32, i32, i32, i32, i32, f32, vp, vp)
 _sig("ser_add_noise_snr", i32, vp, i32, i32, vp, C.c_ulonglong, vp, vp, vp)
 _sig("ser_dropout", i32, vp, C.c_longlong, vp, C.c_uint, f32, vp, vp)
 _sig("ser_adamw_multi", i32, vp, vp, vp, vp, i32, vp, f32, f32, f32, vp)
+_sig("ser_adamw_multi_gated", i32, vp, vp, vp, vp, vp, i32, vp, f32, f32, f32, vp)
 _sig("ser_gemm_tile_hint", i32, C.c_longlong, i32, i32, i32)
 _sig("ser_gemm_tile_hint_mode", i32, C.c_longlong, i32, i32, i32, i32)
 _sig("ser_debug_set_gemm_bm", i32, i32)

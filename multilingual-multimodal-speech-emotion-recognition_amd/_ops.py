@@ -560,17 +560,26 @@ def dropout_(x, dctx, site):
 
 
 def adamw_multi_(segments, hyper, b1, b2, eps):
-    """segments: list of (p, g, m, v, lr_mult, weight_decay) flat fp32 tensors -> one launch per 16 segments."""
+    """segments: list of (p, g, m, v, lr_mult, weight_decay[, gate]) flat fp32 tensors -> one launch per 16 segments.  gate: an
+    int32 device tensor (one element) or None; a segment whose gate is non-zero when the kernel runs is left untouched."""
     import ctypes as C
     n = len(segments)
     ptrs = (C.c_void_p * (4 * n))()
+    gates = (C.c_void_p * n)()
     cnt = (C.c_longlong * n)()
     lrm = (C.c_float * n)()
     wd = (C.c_float * n)()
-    for i, (p, g, m, v, lr_mult, weight_decay) in enumerate(segments):
+    gated = False
+    for i, sg in enumerate(segments):
+        p, g, m, v, lr_mult, weight_decay = sg[:6]
         ptrs[4 * i], ptrs[4 * i + 1], ptrs[4 * i + 2], ptrs[4 * i + 3] = L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v)
         cnt[i], lrm[i], wd[i] = p.numel(), lr_mult, weight_decay
-    L.check(L.lib.ser_adamw_multi(ptrs, cnt, lrm, wd, n, L.ptr(hyper), b1, b2, eps, L.stream_ptr()), "ser_adamw_multi")
+        if len(sg) > 6 and sg[6] is not None:
+            assert sg[6].dtype == torch.int32 and sg[6].numel() == 1
+            gates[i] = sg[6].data_ptr()
+            gated = True
+    L.check(L.lib.ser_adamw_multi_gated(ptrs, cnt, lrm, wd, gates if gated else None, n, L.ptr(hyper), b1, b2, eps, L.stream_ptr()),
+            "ser_adamw_multi")
 
 
 def adamw_(p, g, m, v, hyper, lr_mult, weight_decay, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -151,20 +151,38 @@ __global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const int64_t*
   for (int d = threadIdx.x; d < D; d += blockDim.x)
     e[(long long)row * D + d] = (wemb[id * D + d] + temb[d]) + pemb[p * D + d];
 }
-// scatter-add; rows whose index is the padding index leave that table untouched (nn.Embedding(padding_idx))
+// Scatter-add without atomics (results do not depend on the order workgroups run in: reruns, replicas and a captured step
+// agree bit for bit): the first token row that uses an index owns it and adds up the gradients of all rows with that index
+// in increasing row order.  Rows whose index is the padding index leave that table untouched (nn.Embedding(padding_idx)); the
+// token-type table has one row (type 0), owned by row 0.
 __global__ void embed_bwd_kernel(const float* __restrict__ de, const int64_t* __restrict__ ids, const int64_t* __restrict__ pos,
                                  int rows, int D, int vocab, int max_pos, int pad_id, float* __restrict__ dw, float* __restrict__ dp,
                                  float* __restrict__ dt) {
   const int row = blockIdx.x;
   if (row >= rows) return;
-  long long id = ids[row], p = pos[row];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  p = p < 0 ? 0 : (p >= max_pos ? max_pos - 1 : p);
+  auto wid = [&](int r) { const long long v = ids[r]; return v < 0 ? 0ll : (v >= vocab ? (long long)vocab - 1 : v); };
+  auto pid = [&](int r) { const long long v = pos[r]; return v < 0 ? 0ll : (v >= max_pos ? (long long)max_pos - 1 : v); };
+  const long long id = wid(row), p = pid(row);
+  bool own_w = id != pad_id, own_p = p != pad_id;
+  const bool own_t = row == 0;
+  for (int r = 0; r < row && (own_w || own_p); ++r) {
+    if (wid(r) == id) own_w = false;
+    if (pid(r) == p) own_p = false;
+  }
+  if (!(own_w || own_p || own_t)) return;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    const float g = de[(long long)row * D + d];
-    if (id != pad_id) atomicAdd(dw + id * D + d, g);
-    if (p != pad_id) atomicAdd(dp + p * D + d, g);
-    atomicAdd(dt + d, g);
+    float sw = 0.f, sp = 0.f, st = 0.f;
+    for (int r = row; r < rows; ++r) {
+      const bool mw = own_w && wid(r) == id, mp = own_p && pid(r) == p;
+      if (!(mw || mp || own_t)) continue;
+      const float g = de[(long long)r * D + d];
+      if (mw) sw += g;
+      if (mp) sp += g;
+      if (own_t) st += g;
+    }
+    if (own_w) dw[id * D + d] += sw;
+    if (own_p) dp[p * D + d] += sp;
+    if (own_t) dt[d] += st;
   }
 }
 

@@ -1143,6 +1143,7 @@ struct AdamwSeg {
   float* p; const float* g; float* m; float* v;
   long long n;
   float lr_mult, wd;
+  const int* gate;   // optional device word: non-zero = this segment takes no update in this step (LayerDrop skipped its layer)
 };
 struct AdamwBatch {
   AdamwSeg s[ADAMW_MAX_SEG];
@@ -1150,6 +1151,7 @@ struct AdamwBatch {
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamwBatch bt, const float* __restrict__ hyper, float b1,
                                                           float b2, float eps) {
   const AdamwSeg sg = bt.s[blockIdx.y];
+  if (sg.gate != nullptr && *sg.gate != 0) return;   // torch.optim.AdamW leaves a parameter without a gradient untouched (moments too)
   const float lr = hyper[0] * sg.lr_mult, bc1 = hyper[1], bc2s = hyper[2];
   const float step = lr / bc1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < sg.n; i += (long long)gridDim.x * blockDim.x) {
@@ -1446,9 +1448,11 @@ extern "C" int ser_dropout(const float* x, long long n, const void* state, unsig
   return SER_OK;
 }
 
-// ptrs = host array {p, g, m, v} per segment, n = elements per segment, lr_mult / weight_decay per segment
-extern "C" int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay,
-                               int nseg, const float* hyper, float beta1, float beta2, float eps, void* stream) {
+// ptrs = host array {p, g, m, v} per segment, n = elements per segment, lr_mult / weight_decay per segment; gates = optional host
+// array of device pointers (null entries allowed): a segment whose word is non-zero when the kernel runs is left untouched
+extern "C" int ser_adamw_multi_gated(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay,
+                                     const void* const* gates, int nseg, const float* hyper, float beta1, float beta2, float eps,
+                                     void* stream) {
   for (int s0 = 0; s0 < nseg; s0 += ADAMW_MAX_SEG) {
     const int cnt = nseg - s0 < ADAMW_MAX_SEG ? nseg - s0 : ADAMW_MAX_SEG;
     AdamwBatch bt;
@@ -1457,7 +1461,7 @@ extern "C" int ser_adamw_multi(const void* const* ptrs, const long long* n, cons
     for (int i = 0; i < cnt; ++i) {
       const int k = s0 + i;
       bt.s[i] = AdamwSeg{(float*)ptrs[4 * k], (const float*)ptrs[4 * k + 1], (float*)ptrs[4 * k + 2], (float*)ptrs[4 * k + 3],
-                         n[k], lr_mult[k], weight_decay[k]};
+                         n[k], lr_mult[k], weight_decay[k], gates ? (const int*)gates[k] : nullptr};
       if (n[k] > nmax) nmax = n[k];
     }
     if (nmax <= 0) continue;
@@ -1466,6 +1470,11 @@ extern "C" int ser_adamw_multi(const void* const* ptrs, const long long* n, cons
     SER_LAUNCH_CHECK();
   }
   return SER_OK;
+}
+
+extern "C" int ser_adamw_multi(const void* const* ptrs, const long long* n, const float* lr_mult, const float* weight_decay,
+                               int nseg, const float* hyper, float beta1, float beta2, float eps, void* stream) {
+  return ser_adamw_multi_gated(ptrs, n, lr_mult, weight_decay, nullptr, nseg, hyper, beta1, beta2, eps, stream);
 }
 
 extern "C" int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float lr_mult,

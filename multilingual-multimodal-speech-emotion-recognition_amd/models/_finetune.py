@@ -377,7 +377,13 @@ class _Dropout(torch.autograd.Function):
 
 
 class Noise:
-    """What one forward of one encoder draws.  `plan()` fixes the host decisions (LayerDrop, SpecAugment) for a batch."""
+    """What one forward of one encoder draws.  `plan()` fixes the host decisions (LayerDrop, SpecAugment) for a batch.
+
+    Two ways of applying them: the eager forward calls `plan()` itself and acts on the host values (a skipped layer is not
+    run).  A captured forward cannot branch on the host, so there the owner of the graph calls `plan()` + `stage()` BEFORE each
+    replay (`static = True`: the forward draws nothing): the decisions travel as device words - `skip_dev[l]` non-zero = layer l
+    is dropped, `spec_dev[b * S + t]` = frame masked - every layer is computed and a dropped one discarded by a select, and the
+    optimizer leaves its parameters alone through the same words (FlatAdamW.set_gates)."""
 
     def __init__(self, cfg, enc_index, seed=0):
         import numpy as np
@@ -393,6 +399,9 @@ class Noise:
             self.p_hidden, self.p_attn, self.p_act = g("hidden_dropout_prob"), g("attention_probs_dropout_prob"), 0.0
             self.p_featproj, self.layerdrop, self.spec = 0.0, 0.0, False
         self.skip, self.spec_mask = set(), None
+        self.static = False
+        self.skip_dev = self.spec_dev = None
+        self._shape = None
 
     def site(self, layer, k):
         return SITE0 + 500 * self.enc + 8 * layer + k
@@ -400,6 +409,7 @@ class Noise:
     def plan(self, n_layers, B, S):
         """Host draws for this batch: layers to skip (hf wav2vec2 :700-703) and SpecAugment rows (one batch-1 call per clip,
         as the reference's per-utterance loop makes them: hf :1293-1302 with _compute_mask_indices :101-218)."""
+        self._shape = (n_layers, B, S)
         self.skip = {l for l in range(n_layers) if self.layerdrop > 0 and self.rng.random() < self.layerdrop}
         self.spec_mask = None
         if self.spec and S >= self.mask_len:
@@ -418,6 +428,35 @@ class Noise:
                     m[b, st:st + self.mask_len] = True
             self.spec_mask = m
         return self
+
+    def stage(self, device):
+        """The planned decisions as device words (call outside a capture, before the replay that reads them)."""
+        import numpy as np
+        n_layers, B, S = self._shape
+        if self.skip_dev is None or self.skip_dev.numel() != n_layers or self.skip_dev.device != torch.device(device):
+            self.skip_dev = torch.zeros(n_layers, dtype=torch.int32, device=device)
+        if self.spec_dev is None or self.spec_dev.numel() != B * S or self.spec_dev.device != torch.device(device):
+            self.spec_dev = torch.zeros(B * S, dtype=torch.bool, device=device)
+        sk = np.zeros(n_layers, dtype=np.int32)
+        sk[list(self.skip)] = 1
+        self.skip_dev.copy_(torch.from_numpy(sk), non_blocking=False)
+        m = self.spec_mask if self.spec_mask is not None else np.zeros((B, S), dtype=bool)
+        self.spec_dev.copy_(torch.from_numpy(np.ascontiguousarray(m.reshape(B * S))), non_blocking=False)
+        return self
+
+    def state(self):
+        return self.rng.bit_generator.state
+
+    def set_state(self, st):
+        self.rng.bit_generator.state = st
+
+
+def wav2vec2_frames(cfg, T):
+    """Frames the conv stack makes of T samples (hf :1113-1130)."""
+    n = int(T)
+    for k, s_ in zip(cfg.conv_kernel, cfg.conv_stride):
+        n = (n - k) // s_ + 1
+    return n
 
 
 def _drop(x, noise, p, site):
@@ -510,9 +549,14 @@ def wav2vec2_forward(model, wave, noise=None):
     z = linear(e, p["feature_projection.projection.weight"], p["feature_projection.projection.bias"])       # [B*S, H]
     H = z.shape[1]
     if noise is not None:
-        noise.plan(c.num_hidden_layers, B, S)
+        if not noise.static:
+            noise.plan(c.num_hidden_layers, B, S)
+        else:
+            assert noise._shape == (c.num_hidden_layers, B, S), "Noise.plan() / stage() were not called for this batch shape"
         z = _drop(z, noise, noise.p_featproj, SITE0 + 400)
-        if noise.spec_mask is not None:               # SpecAugment (hf :1293-1302): masked frames <- masked_spec_embed (a select, no arithmetic)
+        if noise.static:                              # device words staged by the graph's owner (all False: nothing masked)
+            z = torch.where(noise.spec_dev[:, None], p["masked_spec_embed"][None, :].to(z.dtype), z)
+        elif noise.spec_mask is not None:             # SpecAugment (hf :1293-1302): masked frames <- masked_spec_embed (a select, no arithmetic)
             mk = torch.from_numpy(noise.spec_mask.reshape(B * S)).to(z.device)
             z = torch.where(mk[:, None], p["masked_spec_embed"][None, :].to(z.dtype), z)
     # positional conv: weight_norm(dim=2) W = g * v / ||v||_(0,1); grouped conv, padding K/2, last frame dropped when K is even
@@ -535,6 +579,12 @@ def wav2vec2_forward(model, wave, noise=None):
     if noise is not None:
         h = _drop(h, noise, noise.p_hidden, SITE0 + 401)
     for i in range(c.num_hidden_layers):
+        if noise is not None and noise.static and noise.layerdrop > 0:
+            # captured step: the layer always runs; a dropped layer's output is discarded by a select on a device word (its
+            # backward then sees zeros, and the optimizer leaves its parameters untouched through the same word)
+            hn = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i)
+            h = torch.where(noise.skip_dev[i] != 0, h, hn)
+            continue
         if noise is not None and i in noise.skip:     # LayerDrop (hf :700-703)
             continue
         h = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i)
@@ -553,7 +603,8 @@ def xlmr_forward(model, ids, attn_mask, noise=None):
                      p["embeddings.token_type_embeddings.weight"], pad)
     h = layer_norm(e, p["embeddings.LayerNorm.weight"], p["embeddings.LayerNorm.bias"], c.layer_norm_eps)
     if noise is not None:
-        noise.plan(c.num_hidden_layers, B, S)
+        if not noise.static:
+            noise.plan(c.num_hidden_layers, B, S)
         h = _drop(h, noise, noise.p_hidden, SITE0 + 500 + 402)
     mask = attn_mask.to(torch.float32).contiguous()
     for i in range(c.num_hidden_layers):

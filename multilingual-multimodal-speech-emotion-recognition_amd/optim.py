@@ -29,6 +29,7 @@ class FlatAdamW:
         self._state = {}              # id(bucket) or id(param) -> (m, v)
         self.hyper = None
         self._host = None
+        self.gates = {}               # id(param) -> one-element int32 device tensor: non-zero = no update in this step (set_gates)
 
     # ---- planning: group -> contiguous segments of flat buckets (+ loose tensors) ------------------------------
     def _build_plan(self):
@@ -50,6 +51,12 @@ class FlatAdamW:
                     segs.append([b, start, end])
             plan.append((grp, segs, loose))
         self._plan = plan
+
+    def set_gates(self, gates):
+        """gates: {id(param): one-element int32 device tensor}.  A gated parameter whose word is non-zero when the update kernel
+        runs is left untouched, moments included - torch.optim.AdamW's treatment of a parameter whose gradient is None, for steps
+        that cannot express "no gradient" by leaving the kernel out (captured graphs: LayerDrop, models/_finetune.py)."""
+        self.gates = dict(gates)
 
     def _mv(self, key, like):
         if key not in self._state:
@@ -86,7 +93,7 @@ class FlatAdamW:
                 if p.grad is None:
                     continue
                 m, v = self._mv(id(p), p.data)
-                segs_all.append((p.data, p.grad.contiguous(), m, v, grp["lr_mult"], grp["weight_decay"]))
+                segs_all.append((p.data, p.grad.contiguous(), m, v, grp["lr_mult"], grp["weight_decay"], self.gates.get(id(p))))
         if segs_all:
             O.adamw_multi_(segs_all, self.hyper, b1, b2, self.eps)
 

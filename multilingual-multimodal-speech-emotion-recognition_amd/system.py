@@ -142,6 +142,44 @@ class SERSystem(nn.Module):
         a_mask = self._ones_mask(a_seq)
         return a_seq, a_mask, t_seq, attn_mask.to(device=a_seq.device, dtype=torch.float32)
 
+    # ---- the encoders' training-mode noise under a captured step (models/_finetune.py Noise) -------------------------
+    def encoder_noises(self):
+        """[(encoder module, its Noise)] for the encoders whose training-mode noise is on (created on first use)."""
+        from .models._finetune import Noise
+        out = []
+        for idx, m in enumerate((self.audio_encoder, self.text_encoder)):
+            if self.training and getattr(m, "encoder_train_noise", False):
+                if getattr(m, "_noise", None) is None:
+                    m._noise = Noise(m.encoder.config, idx, seed=getattr(m, "noise_seed", 0))
+                out.append((m, m._noise))
+        return out
+
+    def stage_encoder_noise(self, wave_shape, ids_shape, device):
+        """Draw this batch's LayerDrop / SpecAugment decisions on the host (same generator, same order as the eager forward) and
+        stage them as device words for a captured forward.  Call once per step, before the replay."""
+        from .models._finetune import wav2vec2_frames
+        for m, noise in self.encoder_noises():
+            cfg = m.encoder.config
+            if noise.enc == 0:
+                noise.plan(cfg.num_hidden_layers, int(wave_shape[0]), wav2vec2_frames(cfg, wave_shape[1]))
+            else:
+                noise.plan(cfg.num_hidden_layers, int(ids_shape[0]), int(ids_shape[1]))
+            noise.stage(device)
+
+    def layerdrop_gates(self):
+        """{id(parameter): device word} for FlatAdamW.set_gates: the parameters of transformer layer l of an encoder with
+        LayerDrop follow `skip_dev[l]` (a dropped layer's parameters take no update, as with torch's `grad is None`)."""
+        import re
+        gates = {}
+        for m, noise in self.encoder_noises():
+            if noise.layerdrop <= 0 or noise.skip_dev is None or getattr(m, "freeze_base", True):
+                continue
+            for name, p_ in m.encoder.named_parameters():
+                mt = re.match(r"encoder\.layers?\.(\d+)\.", name)
+                if mt:
+                    gates[id(p_)] = noise.skip_dev[int(mt.group(1)):int(mt.group(1)) + 1]
+        return gates
+
     def _ones_mask(self, seq):
         """[B, S] of ones (HF returns no attention mask for wav2vec2-base: ref audio_encoder.py:162-163), cached per shape so a
         step does not launch a fill kernel for it."""
@@ -222,11 +260,17 @@ class SERSystem(nn.Module):
         is in training mode with `train_dropout`; otherwise the identity."""
         if not (self.training and self.train_dropout):
             return _ops.dropout_scope(None)
+        self._dropout_word().add_(1)                              # one launch; captured with the step, so replays advance it
+        return _ops.dropout_scope(self._drop_state)
+
+    def _dropout_word(self):
+        """The device word of the dropout generator (None when training-mode dropout is off)."""
+        if not (self.training and self.train_dropout):
+            return None
         dev = next(self.classifier.parameters()).device
         if self._drop_state is None or self._drop_state.device != dev:
             self._drop_state = torch.full((1,), int(self.dropout_seed), dtype=torch.int64, device=dev)
-        self._drop_state.add_(1)                                  # one launch; captured with the step, so replays advance it
-        return _ops.dropout_scope(self._drop_state)
+        return self._drop_state
 
     def loss_from_encoded(self, a_enc, t_enc, attn_mask, labels, use_proto=True, split=False, gate_features=None):
         """Everything trainable: adapters -> cross-attention -> pooling -> fusion -> classifier -> loss.
@@ -514,6 +558,9 @@ class TrainStepper:
         if self.sys.gates_on() and lid is None:
             lid = self.sys.language_features(None, wave.shape[0]).to(dev)
         if not self.use_graph:
+            for _, n in self.sys.encoder_noises():                # host decisions, taken inside the forward
+                n.static = False
+            gates, self.opt.gates = self.opt.gates, {}            # a dropped layer's parameters simply have no gradient here
             self.opt.zero_grad(set_to_none=True)
             if self.reducer:
                 self.reducer.arm()
@@ -522,6 +569,7 @@ class TrainStepper:
                 self.reducer.finish()
             self.opt.prepare_step(dev)
             self.opt.launch()
+            self.opt.gates = gates
         else:
             key = (tuple(wave.shape), tuple(ids.shape))
             if key not in self._graphs:
@@ -539,6 +587,9 @@ class TrainStepper:
             self.static, self.g_fb, self.g_b, self.loss, self.logits = self._graphs[key]
             for p_, g_ in getattr(self, "_loose_grads", ()):      # a caller's zero_grad(set_to_none=True) must not detach them
                 p_.grad = g_
+            for _, n in self.sys.encoder_noises():
+                n.static = True
+            self.sys.stage_encoder_noise(wave.shape, ids.shape, dev)   # this step's LayerDrop / SpecAugment draws (no-op without noise)
             for s, t in zip(self.static, (wave, ids, mask, labels) + ((lid,) if lid is not None else ())):
                 s.copy_(t, non_blocking=True)
             self.g_fb.replay()
@@ -562,6 +613,28 @@ class TrainStepper:
     def _capture_impl(self, wave, ids, mask, labels, lid=None):
         dev = wave.device
         self.sys.prepare()
+        noises = self.sys.encoder_noises()
+        if not noises:
+            return self._capture_body(wave, ids, mask, labels, lid)
+        # the encoders' own noise: host decisions become device words (Noise.static).  The warm-up passes and the capture must
+        # not use up draws, or a captured run would see other masks than eager stepping with the same seeds: the host generators
+        # and the dropout word are put back afterwards
+        drop = self.sys._dropout_word()
+        saved = [n.state() for _, n in noises], (drop.clone() if drop is not None else None)
+        for _, n in noises:
+            n.static = True
+        self.sys.stage_encoder_noise(wave.shape, ids.shape, dev)
+        self.opt.set_gates(self.sys.layerdrop_gates())            # before the optimizer launch is captured
+        try:
+            self._capture_body(wave, ids, mask, labels, lid)
+        finally:
+            for (_, n), st in zip(noises, saved[0]):
+                n.set_state(st)
+            if drop is not None:
+                drop.copy_(saved[1])
+
+    def _capture_body(self, wave, ids, mask, labels, lid=None):
+        dev = wave.device
         self.static = [wave.clone(), ids.clone(), mask.clone(), labels.clone()] + ([lid.clone()] if lid is not None else [])
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

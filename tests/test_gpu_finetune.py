@@ -288,3 +288,61 @@ def test_frozen_encoders_with_training_noise_match_the_oracle():
     with torch.no_grad():
         e = ae.encode(wave.to(dev))
     assert (e.cpu() - clean).abs().max().item() < 5e-4
+
+
+def test_captured_fine_tune_steps_equal_eager_steps_with_the_same_draws():
+    """BASELINE config 3 as hipGraphs: LayerDrop and SpecAugment are host decisions (hf modeling_wav2vec2.py:700-703, :1293-1302),
+    so the captured step computes every layer, discards a dropped one by a select on a device word and gates its parameters'
+    AdamW update with the same word (torch.optim.AdamW leaves a parameter without a gradient untouched).  Against eager stepping
+    with the same seeds - which really skips the layer and really has `grad is None` - losses and every parameter must agree
+    bit for bit over steps that include dropped layers, and the capture's warm-up passes must not use up draws."""
+    import ser_amd  # noqa: F401
+    from transformers import Wav2Vec2Config, XLMRobertaConfig
+    from ser_amd.models import AudioEncoder, TextEncoder
+    from ser_amd.system import SERSystem, TrainStepper
+    dev = torch.device("cuda:0")
+
+    def build():
+        torch.manual_seed(0)
+        wc = Wav2Vec2Config(hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256, conv_dim=[64] * 7,
+                            num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, layerdrop=0.3, mask_time_prob=0.3,
+                            mask_time_length=2, mask_time_min_masks=2)
+        xc = XLMRobertaConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                              max_position_embeddings=66, type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+        ae = AudioEncoder(hf_config=wc, adapter_dim=32, freeze_base=False, use_quality_gates=False, use_audio_conditioning=False)
+        te = TextEncoder(hf_config=xc, adapter_dim=32, freeze_base=False)
+        sysm = SERSystem(ae, te, num_labels=4, shared_dim=64, num_heads=2, proj_dim=64, num_layers=3, base_dim=64).to(dev)
+        sysm.train()
+        for m in (sysm.audio_encoder, sysm.text_encoder):
+            m.encoder_train_noise, m.noise_seed = True, 5
+        return sysm
+
+    g = torch.Generator().manual_seed(11)
+    B, T, S = 3, 4000, 9
+    batches = []
+    for _ in range(5):
+        ids = torch.randint(4, 1000, (B, S), generator=g)
+        ids[:, 0], ids[:, -1] = 0, 2
+        batches.append([0.1 * torch.randn(B, T, generator=g).to(dev), ids.to(dev), torch.ones(B, S).to(dev),
+                        torch.randint(0, 4, (B,), generator=g).to(dev)])
+    runs = {}
+    for mode in ("eager", "graph"):
+        sysm = build()
+        opt = sysm.make_optimizer(lr=1e-3)
+        st = TrainStepper(sysm, opt, use_graph=(mode == "graph"))
+        losses, skipped = [], []
+        for b in batches:
+            losses.append(st.step(*b).clone())
+            skipped.append(sorted(sysm.audio_encoder._noise.skip))
+        torch.cuda.synchronize()
+        runs[mode] = (torch.stack([l.reshape(()) for l in losses]).cpu(), skipped,
+                      {n: p.detach().cpu().clone() for n, p in sysm.named_parameters()}, opt)
+    assert runs["eager"][1] == runs["graph"][1], "the capture must not use up LayerDrop draws"
+    assert any(runs["eager"][1]) and not all(runs["eager"][1]), f"the steps must include dropped and kept layers: {runs['eager'][1]}"
+    assert torch.equal(runs["eager"][0], runs["graph"][0]), f"losses differ: {runs['eager'][0]} vs {runs['graph'][0]}"
+    for n, v in runs["eager"][2].items():
+        assert torch.equal(v, runs["graph"][2][n]), f"{n}: captured and eager stepping diverged ({(v - runs['graph'][2][n]).abs().max():.3e})"
+    # a layer dropped in the first step keeps its initial weights through that step in both modes: covered by the equality above,
+    # and the optimizer's moments of such a parameter stay untouched too
+    oe, og = runs["eager"][3], runs["graph"][3]
+    assert oe.t == og.t == len(batches)
