@@ -1314,6 +1314,16 @@ extern "C" int ser_axpby(const float* x, float a, float b, long long n, float* y
   return SER_OK;
 }
 
+// csrc/xattn_mfma.hip: the same operators on the fp32 matrix pipe (head_dim 32 / 64, <= 256 positions per side)
+int ser_xattn_mfma_ok(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* c, int ldc, int Sq, int Sk,
+                      int head_dim);
+int ser_launch_xattn_fwd_mfma(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const float* key_mask, int B,
+                              int Sq, int Sk, int heads, int head_dim, float* P, float* ctx, int ldc, SerDropout drop, float* P_dropped,
+                              hipStream_t st);
+int ser_launch_xattn_bwd_mfma(const float* dctx, int ldc, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
+                              const float* P, const float* Pv, int B, int Sq, int Sk, int heads, int head_dim, float* dS, float* dq,
+                              int lddq, float* dk, int lddk, float* dv, int lddv, SerDropout drop, hipStream_t st);
+
 extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv,
                              const float* key_mask, int B, int Sq, int Sk, int heads, int head_dim, float* P, float* ctx,
                              int ldc, const void* drop_state, unsigned drop_site, float drop_p, float* P_dropped, void* stream) {
@@ -1323,6 +1333,9 @@ extern "C" int ser_xattn_fwd(const float* q, int ldq, const float* k, int ldk, c
   const long long rows = (long long)B * heads * Sq;
   if (rows <= 0) return SER_OK;
   const SerDropout drop{(const unsigned long long*)drop_state, drop_site, drop_p};
+  if (ser_xattn_mfma_ok(q, ldq, k, ldk, v, ldv, ctx, ldc, Sq, Sk, head_dim))
+    return ser_launch_xattn_fwd_mfma(q, ldq, k, ldk, v, ldv, key_mask, B, Sq, Sk, heads, head_dim, P, ctx, ldc, drop, P_dropped,
+                                     (hipStream_t)stream);
   if ((head_dim == 32 || head_dim == 64) && Sk <= XF_MAXS && Sq <= XF_MAXS) {
     if (head_dim == 32)
       hipLaunchKernelGGL(xattn_fwd_fast_kernel<32>, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, (hipStream_t)stream, q, ldq, k, ldk,
@@ -1351,6 +1364,9 @@ extern "C" int ser_xattn_bwd(const float* dctx, int ldc, const float* q, int ldq
   const bool dropping = drop_state && drop_p > 0.f;
   SER_REQUIRE(!dropping || P_dropped, "xattn_bwd: dropout needs P_dropped from the forward call");
   const float* Pv = dropping ? P_dropped : P;       // weights of dv = Pv^T dctx
+  if (ser_xattn_mfma_ok(q, ldq, k, ldk, v, ldv, dctx, ldc, Sq, Sk, head_dim))
+    return ser_launch_xattn_bwd_mfma(dctx, ldc, q, ldq, k, ldk, v, ldv, P, Pv, B, Sq, Sk, heads, head_dim, dS, dq, lddq, dk, lddk, dv,
+                                     lddv, drop, st);
   if ((head_dim == 32 || head_dim == 64) && Sk <= XF_MAXS && Sq <= XF_MAXS) {
     if (head_dim == 32) {
       hipLaunchKernelGGL(xattn_bwd_q_fast_kernel<32>, dim3(ceil_div(Sq, 16), heads, B), dim3(256), 0, st, dctx, ldc, k, ldk, v, ldv, P,
