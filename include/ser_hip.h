@@ -377,6 +377,9 @@ int ser_colnorm_bwd(const float* dy, const float* x, const float* mean, const fl
                     int L, int Ls, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
 /* Adjoint of the positional conv's window view: dslab[r][c] = sum_j dwin[r - j][j * Cg + c] (hf :326-368). */
 int ser_toeplitz_add(const float* dwin, int rows_win, int K, int Cg, int rows_slab, float* dslab, void* stream);
+/* Adjoint of a strided Conv1d's window view (the feature extractor's layers 1-6, hf :266-300, channels-last rows):
+ * dx[r][c] = sum over taps j with r - j = s m, 0 <= m < M, of dwin[m][j * Cin + c]; every one of the rows_in rows is written. */
+int ser_conv_col2im(const float* dwin, int M, int k, int s, int Cin, long long rows_in, float* dx, void* stream);
 /* XLM-R embeddings word[id] + type[0] + pos[pid] and the scatter-add backward; rows whose index equals pad_id leave
  * that table's gradient untouched (nn.Embedding(padding_idx), hf modeling_xlm_roberta.py:75-121). */
 int ser_embed_fwd(const int64_t* ids, const int64_t* pos, const float* wemb, const float* pemb, const float* temb,

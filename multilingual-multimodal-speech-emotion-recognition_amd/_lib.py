@@ -144,13 +144,17 @@ def split_bf16_il(x):
 _sig("ser_split_bf16_t", i32, vp, i32, i32, i64, vp, vp, i32, vp)
 
 
-def split_bf16_t(x, want_lo=True, pad=64):
-    """fp32 [R, C] device tensor -> split planes of x^T with the R axis zero-padded to a multiple of `pad`:
-    want_lo: ONE interleaved bf16 tensor [C, 2 Rp]; else the hi plane [C, Rp]."""
+def split_bf16_t(x, want_lo=True, pad=64, out=None):
+    """fp32 [R, C] device tensor (rows may be strided: a view like x[j::s]) -> split planes of x^T with the R axis zero-padded to
+    a multiple of `pad`: want_lo: ONE interleaved bf16 tensor [C, 2 Rp]; else the hi plane [C, Rp].  out: a contiguous row block
+    of a larger planes tensor to write into (stacking the transposes of several views under each other)."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
     R, Cc = x.shape
     Rp = (R + pad - 1) // pad * pad
-    out = torch.empty(Cc, (2 if want_lo else 1) * Rp, dtype=torch.bfloat16, device=x.device)
+    if out is None:
+        out = torch.empty(Cc, (2 if want_lo else 1) * Rp, dtype=torch.bfloat16, device=x.device)
+    else:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and tuple(out.shape) == (Cc, (2 if want_lo else 1) * Rp)
     check(lib.ser_split_bf16_t(x.data_ptr(), R, Cc, x.stride(0), out.data_ptr(), out.data_ptr() + 2 * IL_GROUP if want_lo else None, Rp,
                                stream_ptr()), "ser_split_bf16_t")
     return out, Rp

@@ -186,6 +186,26 @@ __global__ void embed_bwd_kernel(const float* __restrict__ de, const int64_t* __
   }
 }
 
+// Input gradient of a strided Conv1d from the per-window gradients: dx[r][c] = sum over taps j with (r - j) = s m, 0 <= m < M of
+// dwin[m][j Cin + c] (channels-last rows; taps added in increasing j: a fixed order, every dx row written, no atomics).
+__global__ void conv_col2im_kernel(const float* __restrict__ dwin, int M, int k, int s, int Cin, long long rows_in,
+                                   float* __restrict__ dx) {
+  const int c4n = Cin >> 2;
+  const long long n = rows_in * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < k; ++j) {
+      const long long t = r - j;
+      if (t < 0 || t % s != 0 || t / s >= M) continue;
+      const float4 v = *(const float4*)(dwin + (t / s) * (long long)k * Cin + (long long)j * Cin + c);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *(float4*)(dx + r * Cin + c) = acc;
+  }
+}
+
 __global__ void wave_normalize_kernel(const float* __restrict__ wave, const float2* __restrict__ stats, int T, long long n,
                                       float* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -254,6 +274,15 @@ extern "C" int ser_embed_fwd(const int64_t* ids, const int64_t* pos, const float
   SER_REQUIRE(ids && pos && wemb && pemb && temb && e && rows > 0 && D > 0, "embed_fwd: bad argument");
   hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, ids, pos, wemb, pemb, temb, rows, D, vocab,
                      max_pos, e);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+/* dwin [M, k Cin] -> dx [rows_in, Cin] (every row written); Cin % 4 == 0 */
+extern "C" int ser_conv_col2im(const float* dwin, int M, int k, int s, int Cin, long long rows_in, float* dx, void* stream) {
+  SER_REQUIRE(dwin && dx && M > 0 && k > 0 && s > 0 && Cin > 0 && Cin % 4 == 0 && rows_in > 0, "conv_col2im: bad argument");
+  const long long n = rows_in * (Cin / 4);
+  hipLaunchKernelGGL(conv_col2im_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dwin, M, k, s, Cin, rows_in, dx);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

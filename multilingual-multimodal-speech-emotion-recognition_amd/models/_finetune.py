@@ -29,6 +29,7 @@ _sig("ser_colnorm_workspace_bytes", L.sz, L.i32, L.i32)
 _sig("ser_colnorm_fwd", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.f32, L.vp, L.vp, L.vp, L.vp, L.vp)
 _sig("ser_colnorm_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp)
 _sig("ser_toeplitz_add", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
+_sig("ser_conv_col2im", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.i64, L.vp, L.vp)
 _sig("ser_embed_fwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 _sig("ser_embed_bwd", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp)
 _sig("ser_wave_normalize", L.i32, L.vp, L.i32, L.i32, L.vp, L.vp, L.vp)
@@ -165,18 +166,30 @@ def padded_lengths(T, kernels, strides):
 class _ConvPad(torch.autograd.Function):
     """Conv1d(C_in -> C_out, kernel k, stride s, no padding, no bias), channels-last, whole batch at once on the padded
     row stride (see padded_lengths): x [rows_in + SLACK, C_in] -> y [rows_out + SLACK, C_out], rows_in = s * rows_out.
-    W2 [C_out, k*C_in] holds the taps in (tap, channel) order.  Forward: one GEMM over the strided window view (row step
-    s*C_in, k*C_in contiguous values: no im2col).  Backward: dW2 = dy^T . windows, one GEMM; dx: one accumulating GEMM per
-    tap, dx[s m + j] += dy[m] . W2[:, j*C_in:(j+1)*C_in] (the rows of one tap never collide, taps follow each other)."""
+    W2 [C_out, k*C_in] holds the taps in (tap, channel) order.
+
+    Channel counts that are multiples of 64 (the 512-channel layers of the Base front end) run on the MFMA tile kernel of the
+    frozen encoders, like `_Linear`: forward = one NT product over the window view of the split planes of x (row step s*C_in,
+    k*C_in contiguous values: no im2col); dW2 = dy^T . windows with the transposed planes of the k strided row subsets x[j::s]
+    stacked under each other; dx = col2im(dy . W2) - the per-window gradients as one product, folded back by a gather kernel.
+    Other shapes keep the head's strided fp32 GEMM: forward over the window view, dW2 one GEMM, dx one accumulating GEMM per tap."""
 
     @staticmethod
     def forward(ctx, x, W2, k, s, rows_out):
         Cin, Cout = x.shape[1], W2.shape[0]
         assert x.shape[0] >= s * (rows_out - 1) + k
-        y = torch.zeros(rows_out + SLACK, Cout, dtype=torch.float32, device=x.device)
-        _gemm(x.data_ptr(), s * Cin, 1, W2.data_ptr(), 1, k * Cin, rows_out, Cout, k * Cin, y, Cout)
+        ctx.tile = Cin % 64 == 0 and Cout % 64 == 0 and rows_out >= 64 and x.is_contiguous()
         ctx.save_for_backward(x, W2)
         ctx.cfg = (k, s, rows_out)
+        if ctx.tile:
+            three = L.lib.ser_get_linear_forward_products() == 3
+            xs, ws = _planes(x, three), _planes(W2.contiguous(), three)
+            y = torch.empty(rows_out + SLACK, Cout, dtype=torch.float32, device=x.device)
+            y[rows_out:].zero_()
+            _nt(xs[1:], s * Cin, ws[1:], k * Cin, rows_out, Cout, k * Cin, y)
+            return y
+        y = torch.zeros(rows_out + SLACK, Cout, dtype=torch.float32, device=x.device)
+        _gemm(x.data_ptr(), s * Cin, 1, W2.data_ptr(), 1, k * Cin, rows_out, Cout, k * Cin, y, Cout)
         return y
 
     @staticmethod
@@ -186,6 +199,24 @@ class _ConvPad(torch.autograd.Function):
         Cin, Cout = x.shape[1], W2.shape[0]
         dy = dy.contiguous()
         dW2 = torch.empty_like(W2)
+        if ctx.tile:
+            three = L.lib.ser_get_head_backward_products() == 3
+            dyv = dy[:rows_out]
+            dyt = _planes_t(dyv, three)                                              # (dy^T)[Cout, Mp]
+            Mp = dyt[3]
+            winT = torch.empty(k * Cin, (2 if three else 1) * Mp, dtype=torch.bfloat16, device=x.device)
+            for j in range(k):                                                       # rows j*Cin.. of windows^T = (x[j::s])^T
+                L.split_bf16_t(x[j::s][:rows_out], three, out=winT[j * Cin:(j + 1) * Cin])
+            wt = (winT.data_ptr(), (winT.data_ptr() + 2 * L.IL_GROUP) if three else None)
+            _nt(dyt[1:3], Mp, wt, Mp, Cout, k * Cin, Mp, dW2)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dys, w2t = _planes(dyv, three), _planes_t(W2.contiguous(), three)    # dwin[M, k Cin] = dy . W2
+                dwin = torch.empty(rows_out, k * Cin, dtype=torch.float32, device=x.device)
+                _nt(dys[1:], Cout, w2t[1:3], w2t[3], rows_out, k * Cin, Cout, dwin)
+                dx = torch.empty_like(x)
+                L.check(L.lib.ser_conv_col2im(L.ptr(dwin), rows_out, k, s, Cin, x.shape[0], L.ptr(dx), L.stream_ptr()), "ser_conv_col2im")
+            return dx, dW2, None, None, None
         _gemm(dy.data_ptr(), 1, Cout, x.data_ptr(), s * Cin, 1, Cout, k * Cin, rows_out, dW2, k * Cin)
         dx = None
         if ctx.needs_input_grad[0]:
