@@ -66,6 +66,11 @@ int ser_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long long n, void
  * when lo == hi + 32, the hi plane alone when lo == NULL.  Gives the K-contiguous NT GEMM the transposed operands of a Linear
  * layer's backward products (dx = dy W, dW = dy^T x) on the fine-tuning path (BASELINE config 3). */
 int ser_split_bf16_t(const float* x, int R, int C, long long ldx, uint16_t* hi, uint16_t* lo, int Rp, void* stream);
+/* ... both operand forms in one pass over x: planes of x [R, C] (s_hi / s_lo, C % 32 == 0) and of x^T [C, Rp] (t_hi / t_lo);
+ * a null lo pointer = that form's hi plane alone (one-product mode).  Used by the fine-tuning Linear layers, whose forward
+ * product reads x and W straight and whose backward products read them (and dy) transposed. */
+int ser_split_bf16_both(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi, uint16_t* t_lo,
+                        int Rp, void* stream);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, split-bf16 operands, fp32 accumulate.
  * Replaces every torch.nn.Linear / Conv1d-as-GEMM inside the frozen encoders

@@ -559,6 +559,17 @@ def dropout_(x, dctx, site):
     return x
 
 
+def dropout(x, dctx, site):
+    """Out of place: y = x * mask / (1 - p) (one launch; `dropout_` on a clone costs a copy more)."""
+    x = _c(x)
+    if dctx is None:
+        return x.clone()
+    state, p = dctx
+    y = torch.empty_like(x)
+    L.check(L.lib.ser_dropout(L.ptr(x), x.numel(), L.ptr(state), int(site), p, L.ptr(y), L.stream_ptr()), "ser_dropout")
+    return y
+
+
 def adamw_multi_(segments, hyper, b1, b2, eps):
     """segments: list of (p, g, m, v, lr_mult, weight_decay[, gate]) flat fp32 tensors -> one launch per 16 segments.  gate: an
     int32 device tensor (one element) or None; a segment whose gate is non-zero when the kernel runs is left untouched."""

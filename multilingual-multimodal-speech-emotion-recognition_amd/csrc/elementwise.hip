@@ -105,6 +105,62 @@ __global__ __launch_bounds__(256) void split_t_kernel(const float* __restrict__ 
     }
   }
 }
+// Both operand forms of one fp32 matrix in ONE pass over it: the planes of x [R, C] (rows of C values, C % 32 == 0) and the
+// planes of x^T [C, Rp] as above.  s_lo / t_lo == nullptr: that form's hi plane alone.  A Linear layer needs x and W straight in
+// its forward product and transposed in its backward products (and dy both ways in backward): one launch instead of two each.
+__global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict__ x, int R, int C, long long ldx, bf16_t* __restrict__ s_hi,
+                                                         bf16_t* __restrict__ s_lo, bf16_t* __restrict__ t_hi, bf16_t* __restrict__ t_lo,
+                                                         int Rp) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const bool s_il = s_lo != nullptr, t_il = t_lo != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    const bool in = r < R && c < C;
+    const float v = in ? x[(long long)r * ldx + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (in) {
+      bf16_t h, l;
+      split_bf16(v, h, l);
+      if (s_il) {
+        const long long o = 2 * ((long long)r * C + c0) + tx;          // il_off(r C + c0 + tx), c0 % 32 == 0 and C % 32 == 0
+        s_hi[o] = h;
+        s_hi[o + SER_IL_GROUP] = l;
+      } else {
+        s_hi[(long long)r * C + c] = h;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i;
+    if (c >= C) continue;
+    bf16_t h, l;
+    split_bf16(tile[tx][ty + 8 * i], h, l);
+    if (t_il) {
+      const long long o = (long long)c * 2 * Rp + 2 * r0 + tx;
+      t_hi[o] = h;
+      t_hi[o + SER_IL_GROUP] = l;
+    } else {
+      t_hi[(long long)c * Rp + r0 + tx] = h;
+    }
+  }
+}
+extern "C" int ser_split_bf16_both(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
+                                   uint16_t* t_lo, int Rp, void* stream) {
+  SER_REQUIRE(x && s_hi && t_hi && R > 0 && C > 0 && C % SER_IL_GROUP == 0 && Rp >= R && Rp % SER_IL_GROUP == 0,
+              "split_bf16_both: bad arguments (R=%d C=%d Rp=%d)", R, C, Rp);
+  SER_REQUIRE((s_lo == nullptr || ser_is_il(s_hi, s_lo)) && (t_lo == nullptr || ser_is_il(t_hi, t_lo)),
+              "split_bf16_both: both planes are written only in the interleaved layout (lo == hi + 32)");
+  hipLaunchKernelGGL(split_both_kernel, dim3(Rp / 32, C / 32), dim3(256), 0, (hipStream_t)stream, x, R, C, ldx, (bf16_t*)s_hi,
+                     (bf16_t*)s_lo, (bf16_t*)t_hi, (bf16_t*)t_lo, Rp);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 extern "C" int ser_split_bf16_t(const float* x, int R, int C, long long ldx, uint16_t* hi, uint16_t* lo, int Rp, void* stream) {
   SER_REQUIRE(x && hi && R > 0 && C > 0 && Rp >= R && Rp % SER_IL_GROUP == 0, "split_bf16_t: bad arguments (R=%d C=%d Rp=%d)", R, C, Rp);
   SER_REQUIRE(lo == nullptr || ser_is_il(hi, lo), "split_bf16_t: both planes are written only in the interleaved layout (lo == hi + 32)");

@@ -72,6 +72,11 @@ def _planes_t(x, three):
     return t, t.data_ptr(), (t.data_ptr() + 2 * L.IL_GROUP) if three else None, Rp
 
 
+def _ptrs(t, three):
+    """(hi, lo) pointers of a planes tensor (interleaved when `three`, else the hi plane alone)."""
+    return t.data_ptr(), (t.data_ptr() + 2 * L.IL_GROUP) if three else None
+
+
 def _nt(a, lda, w, ldw, M, N, K, out, bias=None):
     """out[M,N] fp32 = A[M,K] . W[N,K]^T (+ bias) on the encoder tile kernel (csrc/gemm_bf16.hip); a / w = (hi, lo) pointers."""
     L.check(L.lib.ser_gemm_bf16_nt(a[0], a[1], int(lda), w[0], w[1], int(ldw), int(M), int(N), int(K), L.ptr(bias), L.ACT_NONE, None, 0,
@@ -102,8 +107,17 @@ class _Linear(torch.autograd.Function):
         if not ctx.tile:
             return O.linear_fwd(x, W, b)
         three = L.lib.ser_get_linear_forward_products() == 3
-        xs, ws = _planes(x, three), _planes(W, three)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        if torch.is_grad_enabled() and (x.requires_grad or W.requires_grad):
+            # one pass over x and one over W produce the forward operands AND the transposed ones of the backward products
+            three_b = L.lib.ser_get_head_backward_products() == 3
+            xs, xt, Mp = L.split_bf16_both(x, three, three_b)
+            ws, wt, Np = L.split_bf16_both(W, three, three_b)
+            ctx.planes_t = (xt, Mp, wt, Np, three_b)
+            _nt(_ptrs(xs, three), K, _ptrs(ws, three), K, M, N, K, y, b)
+            return y
+        ctx.planes_t = None
+        xs, ws = _planes(x, three), _planes(W, three)
         _nt(xs[1:], K, ws[1:], K, M, N, K, y, b)
         return y
 
@@ -120,13 +134,19 @@ class _Linear(torch.autograd.Function):
             _wgrad_now(dy, x, dW, db)
             return dx, dW, db
         three = L.lib.ser_get_head_backward_products() == 3
+        saved = ctx.planes_t if (ctx.planes_t is not None and ctx.planes_t[4] == three) else None
+        ctx.planes_t = None
+        if saved is not None:
+            xt, Mp, wt, Np, _ = saved
+        else:
+            (xt, Mp), (wt, Np) = L.split_bf16_t(x, three), L.split_bf16_t(W, three)
+        dys, dyt, Mp2 = L.split_bf16_both(dy, three, three)
+        assert Mp2 == Mp
         dx = None
         if ctx.needs_input_grad[0]:                              # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
-            dys, wt = _planes(dy, three), _planes_t(W, three)
             dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
-            _nt(dys[1:], N, wt[1:3], wt[3], M, K, N, dx)
-        dyt, xt = _planes_t(dy, three), _planes_t(x, three)       # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
-        _nt(dyt[1:3], dyt[3], xt[1:3], xt[3], N, K, dyt[3], dW)
+            _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
+        _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)        # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
         if db is not None:
             ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(N)), dtype=torch.uint8, device=dy.device)
             L.check(L.lib.ser_colsum_tall(L.ptr(dy), M, N, N, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
@@ -395,16 +415,12 @@ class _Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, state, p, site):
         ctx.key = (state, p, site)
-        y = x.clone()
-        O.dropout_(y, (state, p), site)
-        return y
+        return O.dropout(x, (state, p), site)
 
     @staticmethod
     def backward(ctx, dy):
         state, p, site = ctx.key
-        dx = dy.clone()
-        O.dropout_(dx, (state, p), site)
-        return dx, None, None, None
+        return O.dropout(dy, (state, p), site), None, None, None
 
 
 class Noise:

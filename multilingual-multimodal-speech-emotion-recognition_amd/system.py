@@ -128,8 +128,16 @@ class SERSystem(nn.Module):
         if noisy or not (self.audio_encoder.freeze_base and self.text_encoder.freeze_base):
             # BASELINE config 3 (reference freeze_base=False): the fine-tuning form of the encoders, with gradients; also the
             # frozen encoders when their training-mode noise is requested (forward only, same operators)
+            # the two encoders are independent until the cross-attention: the text encoder (a few hundred small launches) runs on a
+            # second stream beside the audio encoder; autograd runs each backward node on the stream of its forward, so the
+            # backward passes overlap the same way
+            ids_d, mask_d = ids.to(wave.device), attn_mask.to(wave.device)
+            if getattr(self, "_enc_side", None) is None:
+                self._enc_side = torch.cuda.Stream()
+            with _ops.fork(self._enc_side) as f:
+                t_seq, t_mask = self.text_encoder.forward_ids(ids_d, mask_d)
             a_seq = self.audio_encoder.encode(wave.to(torch.float32))
-            t_seq, t_mask = self.text_encoder.forward_ids(ids.to(wave.device), attn_mask.to(wave.device))
+            f.join(produced=[t_seq, t_mask], consumed=[ids_d, mask_d])
             a_mask = torch.ones(a_seq.shape[0], a_seq.shape[1], dtype=torch.float32, device=a_seq.device)
             return a_seq, a_mask, t_seq, t_mask
         q_raw = c_raw = None
