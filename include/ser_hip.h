@@ -208,6 +208,11 @@ int ser_encoders_forward(const SerW2vConfig* wcfg, const SerW2vWeights* ww, cons
 int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, long long sbk,
                  long long sbn, int M, int N, int K, const float* bias, int act, const float* residual,
                  int ldr, float* c, int ldc, int accumulate, void* stream);
+/* ... with the number of bf16 MFMA products per multiply chosen by the caller: 3 (as above) or 1 (bf16 operands: what bf16
+ * autocast computes, train.py --use_amp) */
+int ser_gemm_f32_np(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn, int M, int N, int K,
+                    const float* bias, int act, const float* residual, int ldr, float* c, int ldc, int accumulate, int products,
+                    void* stream);
 
 /* The three products of a Linear layer with shape-specialised kernels behind them: M <= 16 rows (the
  * classifier / fusion run at M = batch) stream the weights straight into MFMA operands; wgrad over

@@ -235,6 +235,7 @@ def self_attention(qkv_hi, qkv_lo, key_mask, B, S, heads):
 
 # ---- trainable head (fp32) -------------------------------------------------------------------------
 _sig("ser_gemm_f32", i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, vp)
+_sig("ser_gemm_f32_np", i32, vp, i64, i64, vp, i64, i64, i32, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp)
 _sig("ser_linear_fwd", i32, vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp)
 _sig("ser_linear_wgrad_group_workspace_bytes", sz, C.POINTER(i32), i32)
 _sig("ser_linear_wgrad_group", i32, C.POINTER(vp), C.POINTER(i32), i32, i32, vp, sz, vp)

@@ -446,17 +446,22 @@ def xattn_fwd(q, k, v, key_mask, B, Sq, Sk, heads, dctx=None, site=0):
     return ctx, (P if Pd is None else (P, Pd))
 
 
-def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads, drop=None, site=0):
-    """P: what xattn_fwd returned (the softmax output, or (softmax, dropped) with dropout)."""
+def xattn_bwd(dctx, q, k, v, P, B, Sq, Sk, heads, drop=None, site=0, out=None):
+    """P: what xattn_fwd returned (the softmax output, or (softmax, dropped) with dropout).  out: (dq, dk, dv) to write into -
+    column blocks of a fused buffer are fine (row strides are passed on)."""
     P, Pd = P if isinstance(P, tuple) else (P, None)
     E = q.shape[1]
     hd = E // heads
     dS = torch.empty_like(P)
-    dq, dk, dv = empty(B * Sq, E, like=q), empty(B * Sk, E, like=q), empty(B * Sk, E, like=q)
+    if out is None:
+        dq, dk, dv = empty(B * Sq, E, like=q), empty(B * Sk, E, like=q), empty(B * Sk, E, like=q)
+    else:
+        dq, dk, dv = out
+        assert all(t.stride(1) == 1 and t.dtype == torch.float32 for t in out)
     L.check(L.lib.ser_xattn_bwd(L.ptr(dctx), E, q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(),
-                                v.stride(0), L.ptr(P), B, Sq, Sk, heads, hd, L.ptr(dS), L.ptr(dq), E, L.ptr(dk), E, L.ptr(dv),
-                                E, L.ptr(drop[0] if drop is not None else None), int(site), drop[1] if drop is not None else 0.0,
-                                L.ptr(Pd), L.stream_ptr()), "ser_xattn_bwd")
+                                v.stride(0), L.ptr(P), B, Sq, Sk, heads, hd, L.ptr(dS), dq.data_ptr(), dq.stride(0), dk.data_ptr(),
+                                dk.stride(0), dv.data_ptr(), dv.stride(0), L.ptr(drop[0] if drop is not None else None), int(site),
+                                drop[1] if drop is not None else 0.0, L.ptr(Pd), L.stream_ptr()), "ser_xattn_bwd")
     return dq, dk, dv
 
 

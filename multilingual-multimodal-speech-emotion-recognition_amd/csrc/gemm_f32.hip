@@ -993,15 +993,22 @@ static int launch_gemm_f32_inner(const SerGemmF32Args& gin, hipStream_t st) {
   return SER_OK;
 }
 
-extern "C" int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn,
-                            int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float* c,
-                            int ldc, int accumulate, void* stream) {
+// products: bf16 MFMA products per multiply - 3 (fp32-equivalent) or 1 (bf16 operands, the --use_amp arithmetic)
+extern "C" int ser_gemm_f32_np(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn,
+                               int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float* c,
+                               int ldc, int accumulate, int products, void* stream) {
+  SER_REQUIRE(products == 1 || products == 3, "gemm_f32: products=%d (1 or 3)", products);
   SerGemmF32Args g;
   g.a = a; g.b = b; g.c = c; g.M = M; g.N = N; g.K = K;
   g.sam = sam; g.sak = sak; g.sbk = sbk; g.sbn = sbn; g.ldc = ldc;
   g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr; g.accumulate = accumulate;
-  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0; g.products = 3;
+  g.k_chunk = 0; g.ws = nullptr; g.ws_rowsum = nullptr; g.vec_a = g.vec_b = 0; g.products = products;
   return ser_launch_gemm_f32(g, (hipStream_t)stream);
+}
+extern "C" int ser_gemm_f32(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn,
+                            int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float* c,
+                            int ldc, int accumulate, void* stream) {
+  return ser_gemm_f32_np(a, sam, sak, b, sbk, sbn, M, N, K, bias, act, residual, ldr, c, ldc, accumulate, 3, stream);
 }
 static int gemm_f32_bwd(const float* a, long long sam, long long sak, const float* b, long long sbk, long long sbn, int M, int N,
                         int K, float* c, int ldc, int accumulate, void* stream) {

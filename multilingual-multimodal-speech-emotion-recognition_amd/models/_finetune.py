@@ -35,11 +35,12 @@ _sig("ser_embed_bwd", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32
 _sig("ser_wave_normalize", L.i32, L.vp, L.i32, L.i32, L.vp, L.vp, L.vp)
 
 
-def _gemm(a_ptr, sam, sak, b_ptr, sbk, sbn, M, N, K, c, ldc, bias=None, accumulate=False):
-    """c[M,N] (+)= A . B (+ bias) with element strides (ser_gemm_f32): A[m,k] = a + m*sam + k*sak, B[k,n] = b + k*sbk + n*sbn."""
-    L.check(L.lib.ser_gemm_f32(a_ptr, int(sam), int(sak), b_ptr, int(sbk), int(sbn), int(M), int(N), int(K), L.ptr(bias), L.ACT_NONE, None,
-                               0, c.data_ptr() if isinstance(c, torch.Tensor) else c, int(ldc), 1 if accumulate else 0, L.stream_ptr()),
-            "ser_gemm_f32")
+def _gemm(a_ptr, sam, sak, b_ptr, sbk, sbn, M, N, K, c, ldc, bias=None, accumulate=False, products=3):
+    """c[M,N] (+)= A . B (+ bias) with element strides (ser_gemm_f32): A[m,k] = a + m*sam + k*sak, B[k,n] = b + k*sbk + n*sbn.
+    products: bf16 MFMA products per multiply (3: fp32-equivalent; 1: the --use_amp arithmetic)."""
+    L.check(L.lib.ser_gemm_f32_np(a_ptr, int(sam), int(sak), b_ptr, int(sbk), int(sbn), int(M), int(N), int(K), L.ptr(bias), L.ACT_NONE,
+                                  None, 0, c.data_ptr() if isinstance(c, torch.Tensor) else c, int(ldc), 1 if accumulate else 0,
+                                  int(products), L.stream_ptr()), "ser_gemm_f32")
 
 
 def _wgrad_now(dy, x, dW, db):
@@ -70,6 +71,12 @@ def _planes_t(x, three):
     """fp32 [R, C] -> operand planes of x^T [C, Rp] (R zero-padded to a multiple of 64): (keep-alive, hi, lo, Rp)."""
     t, Rp = L.split_bf16_t(x, three)
     return t, t.data_ptr(), (t.data_ptr() + 2 * L.IL_GROUP) if three else None, Rp
+
+
+# Note (round 3): running a layer's weight-gradient products on a helper stream beside its input-gradient products (a fork / join
+# per backward node) was built and had to be taken out again: with a few hundred such diamonds in one capture, hipStreamEndCapture of
+# ROCm 7.2 recurses without bound (stack overflow; with an unlimited stack > 270 GB of host memory).  The two encoders on two
+# streams (SERSystem.encode) and the head's own forks - a dozen diamonds - are fine.
 
 
 def _ptrs(t, three):
@@ -108,7 +115,7 @@ class _Linear(torch.autograd.Function):
             return O.linear_fwd(x, W, b)
         three = L.lib.ser_get_linear_forward_products() == 3
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        if torch.is_grad_enabled() and (x.requires_grad or W.requires_grad):
+        if any(ctx.needs_input_grad):                             # (grad mode is off inside forward: this is the "will backward run" test)
             # one pass over x and one over W produce the forward operands AND the transposed ones of the backward products
             three_b = L.lib.ser_get_head_backward_products() == 3
             xs, xt, Mp = L.split_bf16_both(x, three, three_b)
@@ -142,13 +149,12 @@ class _Linear(torch.autograd.Function):
             (xt, Mp), (wt, Np) = L.split_bf16_t(x, three), L.split_bf16_t(W, three)
         dys, dyt, Mp2 = L.split_bf16_both(dy, three, three)
         assert Mp2 == Mp
-        dx = None
-        if ctx.needs_input_grad[0]:                              # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
-            dx = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        dx = torch.empty(M, K, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(N)), dtype=torch.uint8, device=dy.device) if db is not None else None
+        if dx is not None:                                       # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
             _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
         _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)        # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
         if db is not None:
-            ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(N)), dtype=torch.uint8, device=dy.device)
             L.check(L.lib.ser_colsum_tall(L.ptr(dy), M, N, N, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
         return dx, dW, db
 
@@ -222,19 +228,18 @@ class _ConvPad(torch.autograd.Function):
         if ctx.tile:
             three = L.lib.ser_get_head_backward_products() == 3
             dyv = dy[:rows_out]
-            dyt = _planes_t(dyv, three)                                              # (dy^T)[Cout, Mp]
-            Mp = dyt[3]
+            Mp = (rows_out + 63) // 64 * 64
             winT = torch.empty(k * Cin, (2 if three else 1) * Mp, dtype=torch.bfloat16, device=x.device)
+            dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+            dwin = torch.empty(rows_out, k * Cin, dtype=torch.float32, device=x.device) if dx is not None else None
+            dys, dyt, Mp2 = L.split_bf16_both(dyv, three, three)                     # dy and (dy^T)[Cout, Mp] in one pass
+            assert Mp2 == Mp
             for j in range(k):                                                       # rows j*Cin.. of windows^T = (x[j::s])^T
                 L.split_bf16_t(x[j::s][:rows_out], three, out=winT[j * Cin:(j + 1) * Cin])
-            wt = (winT.data_ptr(), (winT.data_ptr() + 2 * L.IL_GROUP) if three else None)
-            _nt(dyt[1:3], Mp, wt, Mp, Cout, k * Cin, Mp, dW2)
-            dx = None
-            if ctx.needs_input_grad[0]:
-                dys, w2t = _planes(dyv, three), _planes_t(W2.contiguous(), three)    # dwin[M, k Cin] = dy . W2
-                dwin = torch.empty(rows_out, k * Cin, dtype=torch.float32, device=x.device)
-                _nt(dys[1:], Cout, w2t[1:3], w2t[3], rows_out, k * Cin, Cout, dwin)
-                dx = torch.empty_like(x)
+            _nt(_ptrs(dyt, three), Mp, _ptrs(winT, three), Mp, Cout, k * Cin, Mp, dW2)
+            if dx is not None:
+                w2t = _planes_t(W2.contiguous(), three)                              # dwin[M, k Cin] = dy . W2
+                _nt(_ptrs(dys, three), Cout, w2t[1:3], w2t[3], rows_out, k * Cin, Cout, dwin)
                 L.check(L.lib.ser_conv_col2im(L.ptr(dwin), rows_out, k, s, Cin, x.shape[0], L.ptr(dx), L.stream_ptr()), "ser_conv_col2im")
             return dx, dW2, None, None, None
         _gemm(dy.data_ptr(), 1, Cout, x.data_ptr(), s * Cin, 1, Cout, k * Cin, rows_out, dW2, k * Cin)
@@ -343,6 +348,32 @@ class _Attention(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None, None
 
 
+class _AttentionQKV(torch.autograd.Function):
+    """The same attention on the fused projection output qkv [B*S, 3 H] (q | k | v column blocks): the kernels read the blocks
+    through their row stride and backward writes dq | dk | dv into one [B*S, 3 H] gradient - no slice copies going in and no
+    zero-fill + copy + add per block coming back."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_mask, B, S, heads, drop, site):
+        qkv = qkv.contiguous()
+        H = qkv.shape[1] // 3
+        out, P = O.xattn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], key_mask, B, S, S, heads, drop, site)
+        ctx.P = P
+        ctx.save_for_backward(qkv)
+        ctx.dims = (B, S, heads, drop, site)
+        return out
+
+    @staticmethod
+    def backward(ctx, dctx):
+        (qkv,) = ctx.saved_tensors
+        B, S, heads, drop, site = ctx.dims
+        H = qkv.shape[1] // 3
+        d = torch.empty_like(qkv)
+        O.xattn_bwd(dctx.contiguous(), qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], ctx.P, B, S, S, heads, drop, site,
+                    out=(d[:, :H], d[:, H:2 * H], d[:, 2 * H:]))
+        return d, None, None, None, None, None, None
+
+
 class _Toeplitz(torch.autograd.Function):
     """One group of the positional conv for all clips at once.  slab [B*R + K, Cg]: per clip R = S + K - 1 zero-padded
     rows, clips back to back (+ K rows of slack), so the window rows of every clip are ONE strided view with row step Cg:
@@ -375,6 +406,58 @@ class _Toeplitz(torch.autograd.Function):
             dslab = torch.empty_like(slab)
             L.check(L.lib.ser_toeplitz_add(L.ptr(dwin), rows, K, Cg, slab.shape[0], L.ptr(dslab), L.stream_ptr()), "ser_toeplitz_add")
         return dslab, dW2, db, None, None
+
+
+class _PosConv(torch.autograd.Function):
+    """The whole positional conv (hf :326-368: grouped Conv1d, kernel K, padding K // 2, last frame dropped when K is even) on
+    z [B*S, H] with the weight-normed weight Wp [H, Cg, K]: every group is the window-view product of `_Toeplitz`, but the zero
+    padding, the group split of z and of the weight, and the reassembly of the output happen ONCE for all groups (a padded
+    [G, B*R + K, Cg] slab buffer, one [H, K*Cg] weight matrix, one [G, B*R, Cg] output), in forward and in backward, instead of a
+    pad / cat / slice chain per group on the autograd tape.  Products per multiply follow the Linear layers' setting."""
+
+    @staticmethod
+    def forward(ctx, z, Wp, bias, B, S, K, G):
+        H = z.shape[1]
+        Cg, R = H // G, S + K - 1
+        rows = B * R
+        slabs = torch.zeros(G, rows + K, Cg, dtype=torch.float32, device=z.device)
+        slabs[:, :rows].view(G, B, R, Cg)[:, :, K // 2:K // 2 + S] = z.view(B, S, G, Cg).permute(2, 0, 1, 3)
+        W2 = Wp.permute(0, 2, 1).reshape(H, K * Cg).contiguous()               # taps in (tap, channel) order; rows g*Cg.. = group g
+        bias = bias.contiguous()
+        y = torch.empty(G, rows, Cg, dtype=torch.float32, device=z.device)
+        np_ = L.lib.ser_get_linear_forward_products()
+        for g in range(G):
+            _gemm(slabs[g].data_ptr(), Cg, 1, W2[g * Cg:].data_ptr(), 1, K * Cg, rows, Cg, K * Cg, y[g].data_ptr(), Cg,
+                  bias=bias[g * Cg:(g + 1) * Cg], products=np_)
+        ctx.save_for_backward(slabs, W2)
+        ctx.dims = (B, S, K, G)
+        return y.view(G, B, R, Cg)[:, :, :S].permute(1, 2, 0, 3).reshape(B * S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        slabs, W2 = ctx.saved_tensors
+        B, S, K, G = ctx.dims
+        H = W2.shape[0]
+        Cg, R = H // G, S + K - 1
+        rows = B * R
+        dy = torch.zeros(G, rows, Cg, dtype=torch.float32, device=dout.device)   # rows t >= S of a clip straddle two clips: no gradient
+        dy.view(G, B, R, Cg)[:, :, :S] = dout.reshape(B, S, G, Cg).permute(2, 0, 1, 3)
+        dW2 = torch.empty_like(W2)
+        db = torch.empty(H, dtype=torch.float32, device=dout.device)
+        dslabs = torch.empty_like(slabs) if ctx.needs_input_grad[0] else None
+        np_ = L.lib.ser_get_head_backward_products()
+        for g in range(G):
+            _gemm(dy[g].data_ptr(), 1, Cg, slabs[g].data_ptr(), Cg, 1, Cg, K * Cg, rows, dW2[g * Cg:].data_ptr(), K * Cg, products=np_)
+            L.check(L.lib.ser_colsum(dy[g].data_ptr(), rows, Cg, Cg, db[g * Cg:].data_ptr(), 0, L.stream_ptr()), "ser_colsum")
+        if dslabs is not None:
+            dwin = torch.empty(rows, K * Cg, dtype=torch.float32, device=dout.device)
+            for g in range(G):
+                O.linear_dgrad(dy[g], W2[g * Cg:(g + 1) * Cg], out=dwin)          # [rows, K*Cg]
+                L.check(L.lib.ser_toeplitz_add(L.ptr(dwin), rows, K, Cg, rows + K, dslabs[g].data_ptr(), L.stream_ptr()), "ser_toeplitz_add")
+        dz = None
+        if dslabs is not None:
+            dz = dslabs[:, :rows].view(G, B, R, Cg)[:, :, K // 2:K // 2 + S].permute(1, 2, 0, 3).reshape(B * S, H)
+        return dz, dW2.view(H, K, Cg).permute(0, 2, 1), db, None, None, None, None
 
 
 class _Embed(torch.autograd.Function):
@@ -535,9 +618,8 @@ def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask, noise=No
     Hd = h.shape[1]
     qkv = linear(h, torch.cat([g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight")], dim=0),
                  torch.cat([g(names["q"] + ".bias"), g(names["k"] + ".bias"), g(names["v"] + ".bias")], dim=0))
-    q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
     adrop = O.dropout_ctx(noise.p_attn) if noise is not None else None
-    ctx = _Attention.apply(q, k, v, key_mask, B, S, heads, adrop, noise.site(layer, 0) if noise is not None else 0)
+    ctx = _AttentionQKV.apply(qkv, key_mask, B, S, heads, adrop, noise.site(layer, 0) if noise is not None else 0)
     a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"))
     if noise is not None:
         a = _drop(a, noise, noise.p_hidden, noise.site(layer, 1))
@@ -612,16 +694,7 @@ def wav2vec2_forward(model, wave, noise=None):
     Wp = g0 * v0 / torch.sqrt((v0 * v0).sum(dim=(0, 1), keepdim=True))                                      # [H, Cg, K]
     K, G = c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups
     Cg, R = H // G, S + K - 1
-    zb = z.reshape(B, S, G, Cg)
-    bp = p["encoder.pos_conv_embed.conv.bias"]
-    outs = []
-    for gi in range(G):
-        slab = torch.nn.functional.pad(zb[:, :, gi, :], (0, 0, K // 2, K - 1 - K // 2))                     # [B, R, Cg] zero rows around each clip
-        slab = torch.cat([slab.reshape(B * R, Cg), slab.new_zeros(K, Cg)], dim=0)
-        W2 = Wp[gi * Cg:(gi + 1) * Cg].permute(0, 2, 1).reshape(Cg, K * Cg).contiguous()
-        y = _Toeplitz.apply(slab.contiguous(), W2, bp[gi * Cg:(gi + 1) * Cg].contiguous(), B * R, K)          # [B*R, Cg], bias added in the GEMM
-        outs.append(y.reshape(B, R, Cg)[:, :S, :])
-    pc = torch.cat(outs, dim=2).reshape(B * S, H)
+    pc = _PosConv.apply(z.contiguous(), Wp, p["encoder.pos_conv_embed.conv.bias"], B, S, K, G)
     h = layer_norm(gelu(pc), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps, residual=z)   # LN(z + GELU(conv))
     if noise is not None:
         h = _drop(h, noise, noise.p_hidden, SITE0 + 401)
