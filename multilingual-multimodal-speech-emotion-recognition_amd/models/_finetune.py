@@ -76,7 +76,9 @@ def _planes_t(x, three):
 # Note (round 3): running a layer's weight-gradient products on a helper stream beside its input-gradient products (a fork / join
 # per backward node) was built and had to be taken out again: with a few hundred such diamonds in one capture, hipStreamEndCapture of
 # ROCm 7.2 recurses without bound (stack overflow; with an unlimited stack > 270 GB of host memory).  The two encoders on two
-# streams (SERSystem.encode) and the head's own forks - a dozen diamonds - are fine.
+# streams (SERSystem.encode) and the head's own forks - a dozen diamonds - are fine.  The fork-only variant (helper stream that is
+# joined once per backward pass) captures, but is slower: 28.9 instead of 24.6 ms - every cross-stream edge of a replayed graph
+# costs more than the launch it takes off the chain.
 
 
 def _ptrs(t, three):
