@@ -296,6 +296,15 @@ size_t ser_layernorm_bwd_workspace_bytes(int rows, int D); /* 0 for few rows; el
 int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
                       const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
                       float* dbeta, int accumulate_params, void* workspace, void* stream);
+/* The hidden dropout, the residual add and the LayerNorm of a post-LN transformer block (hf modeling_wav2vec2.py:591-608,
+ * modeling_xlm_roberta.py:300-311) in one pass each way: y = LN(dropout(x) + x2), z = dropout(x) + x2 kept for backward; the mask
+ * of element (row, col) is the one ser_dropout gives element row * D + col with the same (state, site, p).  Backward writes
+ * dx2 = the LayerNorm input gradient and dx = dx2 times the mask. */
+int ser_layernorm_drop_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows, int D, float* y,
+                           float* z, float* mean, float* rstd, const void* drop_state, unsigned drop_site, float drop_p, void* stream);
+int ser_layernorm_drop_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma, int rows, int D,
+                           float* dx, float* dx2, float* dgamma, float* dbeta, int accumulate_params, void* workspace,
+                           const void* drop_state, unsigned drop_site, float drop_p, void* stream);
 
 /* the two chained LayerNorms of a classifier block (classifier.py:209-210) fused: forward keeps
  * stats[4][rows] = mean1, rstd1, mean2, rstd2; backward returns dx = LN1'(LN2'(du) + dres) and all four
@@ -377,6 +386,10 @@ int ser_adamw(float* p, const float* g, float* m, float* v, long long n, const f
  * ------------------------------------------------------------------------------------------- */
 /* dx = dy * d/dx[x Phi(x)] from the pre-activation x (hf activations.py GELUActivation). */
 int ser_gelu_bwd(const float* dy, const float* x, long long n, float* dx, void* stream);
+/* ... of y = dropout(gelu(x)) (the activation dropout of hf Wav2Vec2FeedForward :560-574): the mask of the forward pass
+ * (state, site, element index) multiplies dy in the same pass */
+int ser_gelu_drop_bwd(const float* dy, const float* x, long long n, float* dx, const void* drop_state, unsigned drop_site, float drop_p,
+                      void* stream);
 /* GroupNorm with one channel per group = normalisation over time per (clip, channel); x [B][Ls][C] channels-last, the
  * first L of a clip's Ls rows are its frames, the rest padding (written as zeros) (hf modeling_wav2vec2.py:302-323).
  * workspace: ser_colnorm_workspace_bytes(B, C). */

@@ -17,12 +17,20 @@ static inline unsigned ew_grid(long long n, int per_block = 256) {
 }
 
 // d/dx [x Phi(x)] = Phi(x) + x phi(x)
-__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long n, float* __restrict__ dx) {
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long n, float* __restrict__ dx,
+                                SerDropout drop) {
+  // y = dropout(gelu(x)) when `drop` is active: the mask of element i (the forward pass's triple) multiplies dy first
+  const bool dropping = drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dst = dropping ? *drop.state : 0ull;
+  const unsigned dth = ser_drop_thresh(drop.p);
+  const float dsc = 1.0f / (1.0f - drop.p);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float v = x[i];
     const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * v * v);
-    dx[i] = dy[i] * (cdf + v * pdf);
+    float g = dy[i];
+    if (dropping) g *= ser_drop_mult(dst, drop.site, (unsigned)i, dth, dsc);
+    dx[i] = g * (cdf + v * pdf);
   }
 }
 
@@ -220,7 +228,18 @@ int ser_launch_wave_stats(const float* wave, int B, int T, void* stats, hipStrea
 
 extern "C" int ser_gelu_bwd(const float* dy, const float* x, long long n, float* dx, void* stream) {
   if (n <= 0) return SER_OK;
-  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, x, n, dx);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, x, n, dx, SerDropout{nullptr, 0u, 0.f});
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+/* backward of y = dropout(gelu(x)) (ser_act_drop_fwd with SER_ACT_GELU): dx = dy . mask / (1 - p) . gelu'(x) in one pass */
+extern "C" int ser_gelu_drop_bwd(const float* dy, const float* x, long long n, float* dx, const void* drop_state, unsigned drop_site,
+                                 float drop_p, void* stream) {
+  if (n <= 0) return SER_OK;
+  SER_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gelu_drop_bwd: p=%f out of range", drop_p);
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, dy, x, n, dx,
+                     SerDropout{(const unsigned long long*)drop_state, drop_site, drop_p});
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

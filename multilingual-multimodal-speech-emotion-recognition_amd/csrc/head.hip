@@ -14,11 +14,17 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int rows, int D,
                                                            float* __restrict__ y, float* __restrict__ z,
-                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           SerDropout drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nchunk = D >> 2;
+  // drop active: z = dropout(x) + x2 - the mask of element (row, col) is that of a dropout layer applied to x [rows, D]
+  const bool dropping = drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dst = dropping ? *drop.state : 0ull;
+  const unsigned dth = ser_drop_thresh(drop.p);
+  const float dsc = 1.0f / (1.0f - drop.p);
   float4 v[NV];
   float s = 0.f;
 #pragma unroll
@@ -26,6 +32,13 @@ __global__ __launch_bounds__(256) void ln_fwd_stats_kernel(const float* __restri
     const int c = lane + 64 * i;
     if (c < nchunk) {
       v[i] = *(const float4*)(x + (long long)row * D + c * 4);
+      if (dropping) {
+        const unsigned e0 = (unsigned)((long long)row * D + c * 4);
+        v[i].x = __fmul_rn(v[i].x, ser_drop_mult(dst, drop.site, e0, dth, dsc));
+        v[i].y = __fmul_rn(v[i].y, ser_drop_mult(dst, drop.site, e0 + 1, dth, dsc));
+        v[i].z = __fmul_rn(v[i].z, ser_drop_mult(dst, drop.site, e0 + 2, dth, dsc));
+        v[i].w = __fmul_rn(v[i].w, ser_drop_mult(dst, drop.site, e0 + 3, dth, dsc));
+      }
       if (x2) {
         const float4 w = *(const float4*)(x2 + (long long)row * D + c * 4);
         v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w;
@@ -71,12 +84,18 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ dx_add,
-                                                        int rows, int D, float* __restrict__ dx) {
+                                                        int rows, int D, float* __restrict__ dx, float* __restrict__ dx_drop,
+                                                        SerDropout drop) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nchunk = D >> 2;
   const float mu = mean[row], rs = rstd[row];
+  // dx_drop: the gradient of the dropped addend of z = dropout(x) + x2, i.e. dx times the forward mask (dx itself goes to x2)
+  const bool dropping = dx_drop != nullptr && drop.state != nullptr && drop.p > 0.f;
+  const unsigned long long dst = dropping ? *drop.state : 0ull;
+  const unsigned dth = ser_drop_thresh(drop.p);
+  const float dsc = 1.0f / (1.0f - drop.p);
   float4 xh[NV], dg[NV];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -107,6 +126,16 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const float* __restrict_
         o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
       }
       *(float4*)(dx + (long long)row * D + c * 4) = o;
+      if (dx_drop) {
+        if (dropping) {
+          const unsigned e0 = (unsigned)((long long)row * D + c * 4);
+          o.x *= ser_drop_mult(dst, drop.site, e0, dth, dsc);
+          o.y *= ser_drop_mult(dst, drop.site, e0 + 1, dth, dsc);
+          o.z *= ser_drop_mult(dst, drop.site, e0 + 2, dth, dsc);
+          o.w *= ser_drop_mult(dst, drop.site, e0 + 3, dth, dsc);
+        }
+        *(float4*)(dx_drop + (long long)row * D + c * 4) = o;
+      }
     }
   }
 }
@@ -1188,7 +1217,22 @@ extern "C" int ser_layernorm_fwd(const float* x, const float* x2, const float* g
   if (rows <= 0) return SER_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(ceil_div(rows, 4)), block(256);
-  LN_DISPATCH(ln_fwd_stats_kernel, ceil_div(D / 4, 64), x, x2, gamma, beta, eps, rows, D, y, z, mean, rstd);
+  LN_DISPATCH(ln_fwd_stats_kernel, ceil_div(D / 4, 64), x, x2, gamma, beta, eps, rows, D, y, z, mean, rstd, (SerDropout{nullptr, 0u, 0.f}));
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+// y = LN(dropout(x) + x2): the hidden dropout, the residual add and the LayerNorm of a post-LN transformer block in one pass
+extern "C" int ser_layernorm_drop_fwd(const float* x, const float* x2, const float* gamma, const float* beta, float eps, int rows, int D,
+                                      float* y, float* z, float* mean, float* rstd, const void* drop_state, unsigned drop_site,
+                                      float drop_p, void* stream) {
+  SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_drop_fwd: D=%d unsupported", D);
+  SER_REQUIRE(drop_p >= 0.f && drop_p < 1.f && z, "layernorm_drop_fwd: p=%f out of range, or no z output", drop_p);
+  if (rows <= 0) return SER_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(ceil_div(rows, 4)), block(256);
+  LN_DISPATCH(ln_fwd_stats_kernel, ceil_div(D / 4, 64), x, x2, gamma, beta, eps, rows, D, y, z, mean, rstd,
+              (SerDropout{(const unsigned long long*)drop_state, drop_site, drop_p}));
   SER_LAUNCH_CHECK();
   return SER_OK;
 }
@@ -1198,15 +1242,15 @@ extern "C" size_t ser_layernorm_bwd_workspace_bytes(int rows, int D) {
   return nsl > 1 ? (size_t)nsl * 2 * D * sizeof(float) : 0;
 }
 
-extern "C" int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
-                                 const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
-                                 float* dbeta, int accumulate_params, void* workspace, void* stream) {
+static int layernorm_bwd_impl(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                              const float* dx_add, int rows, int D, float* dx, float* dx_drop, SerDropout drop, float* dgamma,
+                              float* dbeta, int accumulate_params, void* workspace, void* stream) {
   SER_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm_bwd: D=%d unsupported", D);
   if (rows <= 0) return SER_OK;
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
     dim3 grid(ceil_div(rows, 4)), block(256);
-    LN_DISPATCH(ln_bwd_dx_kernel, ceil_div(D / 4, 64), dy, z, mean, rstd, gamma, dx_add, rows, D, dx);
+    LN_DISPATCH(ln_bwd_dx_kernel, ceil_div(D / 4, 64), dy, z, mean, rstd, gamma, dx_add, rows, D, dx, dx_drop, drop);
   }
   if (dgamma && dbeta) {
     const int nsl = (rows >= 512 && workspace) ? 32 : 1;
@@ -1219,6 +1263,22 @@ extern "C" int ser_layernorm_bwd(const float* dy, const float* z, const float* m
   }
   SER_LAUNCH_CHECK();
   return SER_OK;
+}
+
+extern "C" int ser_layernorm_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                                 const float* gamma, const float* dx_add, int rows, int D, float* dx, float* dgamma,
+                                 float* dbeta, int accumulate_params, void* workspace, void* stream) {
+  return layernorm_bwd_impl(dy, z, mean, rstd, gamma, dx_add, rows, D, dx, nullptr, SerDropout{nullptr, 0u, 0.f}, dgamma, dbeta,
+                            accumulate_params, workspace, stream);
+}
+
+// backward of y = LN(dropout(x) + x2): dx2 = the LayerNorm input gradient, dx = dx2 times the forward mask, in the same pass
+extern "C" int ser_layernorm_drop_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                                      int rows, int D, float* dx, float* dx2, float* dgamma, float* dbeta, int accumulate_params,
+                                      void* workspace, const void* drop_state, unsigned drop_site, float drop_p, void* stream) {
+  SER_REQUIRE(dx && dx2 && drop_p >= 0.f && drop_p < 1.f, "layernorm_drop_bwd: bad argument");
+  return layernorm_bwd_impl(dy, z, mean, rstd, gamma, nullptr, rows, D, dx2, dx, SerDropout{(const unsigned long long*)drop_state,
+                            drop_site, drop_p}, dgamma, dbeta, accumulate_params, workspace, stream);
 }
 
 extern "C" int ser_layernorm2_fwd(const float* x, const float* g1, const float* b1, const float* g2, const float* b2,

@@ -25,6 +25,7 @@ from .. import _ops as O
 
 _sig = L._sig
 _sig("ser_gelu_bwd", L.i32, L.vp, L.vp, L.i64, L.vp, L.vp)
+_sig("ser_gelu_drop_bwd", L.i32, L.vp, L.vp, L.i64, L.vp, L.vp, C.c_uint, L.f32, L.vp)
 _sig("ser_colnorm_workspace_bytes", L.sz, L.i32, L.i32)
 _sig("ser_colnorm_fwd", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.f32, L.vp, L.vp, L.vp, L.vp, L.vp)
 _sig("ser_colnorm_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp)
@@ -273,6 +274,35 @@ class _Gelu(torch.autograd.Function):
 gelu = _Gelu.apply
 
 
+class _GeluDrop(torch.autograd.Function):
+    """dropout(gelu(x)) - the FFN activation followed by its activation dropout - as one pass forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, x, state, p, site):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.key = (state, p, site)
+        return O.act_fwd(x, O.ACT_GELU, (state, p), site)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        state, p, site = ctx.key
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib.ser_gelu_drop_bwd(L.ptr(dy), L.ptr(x), x.numel(), L.ptr(dx), L.ptr(state), int(site), float(p), L.stream_ptr()),
+                "ser_gelu_drop_bwd")
+        return dx, None, None, None
+
+
+def gelu_drop(x, noise, p, site):
+    """gelu(x), then the dropout site `site` of an encoder when its noise is on and a dropout scope is active."""
+    d = O.dropout_ctx(p) if (noise is not None and p > 0.0) else None
+    if d is None:
+        return gelu(x)
+    return _GeluDrop.apply(x, d[0], d[1], site)
+
+
 class _LayerNorm(torch.autograd.Function):
     """LN(x (+ x2)) over the last dim on [rows, D]: the head's kernels (saved: the sum, mean, rstd)."""
 
@@ -289,6 +319,55 @@ class _LayerNorm(torch.autograd.Function):
         dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
         dx = O.ln_bwd(dy.contiguous(), (z, mean, rstd), gamma, dg, db)
         return dx, (dx if ctx.two else None), dg, db, None
+
+
+_sig("ser_layernorm_drop_fwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.f32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, C.c_uint, L.f32, L.vp)
+_sig("ser_layernorm_drop_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp, C.c_uint,
+     L.f32, L.vp)
+_sig("ser_layernorm_bwd_workspace_bytes", L.sz, L.i32, L.i32)
+
+
+class _LayerNormDrop(torch.autograd.Function):
+    """LN(dropout(x) + x2) on [rows, D]: hidden dropout, residual add and LayerNorm of a post-LN block as one pass forward and one
+    pass (+ the parameter-gradient reduction) backward - the same values as `_Dropout` followed by `_LayerNorm`."""
+
+    @staticmethod
+    def forward(ctx, x, x2, gamma, beta, eps, state, p, site):
+        x, x2 = x.contiguous(), x2.contiguous()
+        rows, D = x.shape
+        y, z = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L.check(L.lib.ser_layernorm_drop_fwd(L.ptr(x), L.ptr(x2), L.ptr(gamma), L.ptr(beta), eps, rows, D, L.ptr(y), L.ptr(z), L.ptr(mean),
+                                             L.ptr(rstd), L.ptr(state), int(site), float(p), L.stream_ptr()), "ser_layernorm_drop_fwd")
+        ctx.save_for_backward(z, mean, rstd, gamma)
+        ctx.key = (state, p, site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, mean, rstd, gamma = ctx.saved_tensors
+        state, p, site = ctx.key
+        dy = dy.contiguous()
+        rows, D = dy.shape
+        dx, dx2 = torch.empty_like(dy), torch.empty_like(dy)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        nb = L.lib.ser_layernorm_bwd_workspace_bytes(rows, D)
+        ws = torch.empty(nb, dtype=torch.uint8, device=dy.device) if nb else None
+        L.check(L.lib.ser_layernorm_drop_bwd(L.ptr(dy), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), rows, D, L.ptr(dx), L.ptr(dx2),
+                                             L.ptr(dg), L.ptr(db), 0, L.ptr(ws), L.ptr(state), int(site), float(p), L.stream_ptr()),
+                "ser_layernorm_drop_bwd")
+        return dx, dx2, dg, db, None, None, None, None
+
+
+def layer_norm_drop(x, gamma, beta, eps, residual, noise, p, site):
+    """LN(dropout_site(x) + residual); plain LN(x + residual) when the encoder's noise is off or no dropout scope is active."""
+    d = O.dropout_ctx(p) if (noise is not None and p > 0.0) else None
+    if d is None:
+        return layer_norm(x, gamma, beta, eps, residual=residual)
+    shp = x.shape
+    y = _LayerNormDrop.apply(x.reshape(-1, shp[-1]), residual.reshape(-1, shp[-1]), gamma, beta, eps, d[0], d[1], site)
+    return y.reshape(shp)
 
 
 def layer_norm(x, gamma, beta, eps, residual=None):
@@ -623,16 +702,12 @@ def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask, noise=No
     adrop = O.dropout_ctx(noise.p_attn) if noise is not None else None
     ctx = _AttentionQKV.apply(qkv, key_mask, B, S, heads, adrop, noise.site(layer, 0) if noise is not None else 0)
     a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"))
-    if noise is not None:
-        a = _drop(a, noise, noise.p_hidden, noise.site(layer, 1))
-    h = layer_norm(a, g(names["ln1"] + ".weight"), g(names["ln1"] + ".bias"), eps, residual=h)
-    f = gelu(linear(h, g(names["f1"] + ".weight"), g(names["f1"] + ".bias")))
-    if noise is not None:
-        f = _drop(f, noise, noise.p_act, noise.site(layer, 2))
+    ph = noise.p_hidden if noise is not None else 0.0
+    st = (lambda k: noise.site(layer, k)) if noise is not None else (lambda k: 0)
+    h = layer_norm_drop(a, g(names["ln1"] + ".weight"), g(names["ln1"] + ".bias"), eps, h, noise, ph, st(1))
+    f = gelu_drop(linear(h, g(names["f1"] + ".weight"), g(names["f1"] + ".bias")), noise, noise.p_act if noise is not None else 0.0, st(2))
     f = linear(f, g(names["f2"] + ".weight"), g(names["f2"] + ".bias"))
-    if noise is not None:
-        f = _drop(f, noise, noise.p_hidden, noise.site(layer, 3))
-    return layer_norm(f, g(names["ln2"] + ".weight"), g(names["ln2"] + ".bias"), eps, residual=h)
+    return layer_norm_drop(f, g(names["ln2"] + ".weight"), g(names["ln2"] + ".bias"), eps, h, noise, ph, st(3))
 
 
 W2V = dict(q="attention.q_proj", k="attention.k_proj", v="attention.v_proj", o="attention.out_proj", ln1="layer_norm",

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Shader clock seen by a latency-bound probe wave while the REAL schedule runs (not a synthetic partner): short probes
-(~0.3 ms of dependent FMAs on 8 waves, one per XCD by round-robin placement) are launched on their own stream every
-`every` pipelined steps, never synchronised, each into its own slot; read at the end.  Three loads: the pipelined training
+(~1.5 ms of dependent FMAs on 8 waves, one per XCD by round-robin placement) run on their own stream, each started by an event
+behind every `every`-th pipelined step and never waited for, each into its own slot; read at the end.  Runs are long enough
+(seconds) to show the clock settling: the chip holds its top clock for a while after an idle or light phase before the power
+management pulls it down.  Three loads: the pipelined training
 step, the encoder graph alone back to back, the head graph alone back to back.
 usage: clock_under_load.py [group] [steps]"""
 import os, sys, time
@@ -31,14 +33,21 @@ probe_stream = torch.cuda.Stream()
 
 
 def run(name, body, n, every):
+    """`n` calls of `body`; after every `every`-th call a probe is queued that starts when THAT call has finished on the device (an
+    event on the main stream), i.e. it runs beside the calls that follow - probes are spread over the whole run in device time, not
+    bunched at its start (the host runs far ahead of the device)."""
     slots = n // every + 1
     out = torch.zeros(slots, 8, 2, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
+    cur = torch.cuda.current_stream()
     t0 = time.perf_counter()
     k = 0
     for i in range(n):
         body()
         if i % every == every - 1:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            probe_stream.wait_event(ev)
             with torch.cuda.stream(probe_stream):
                 L.check(fn(out[k].data_ptr(), 8, 100000, probe_stream.cuda_stream), "probe")
             k += 1
@@ -47,16 +56,16 @@ def run(name, body, n, every):
     v = out[:k].cpu().double()
     ghz = (v[..., 0] / v[..., 1].clamp(min=1) * 0.1)
     per_probe = ghz.median(dim=1).values
-    us = v[..., 1].median(dim=1).values * 0.01
+    q = max(1, k // 4)
+    series = ", ".join(f"{float(per_probe[j * k // 8:(j + 1) * k // 8 or 1].median()):.2f}" for j in range(8)) if k >= 8 else ""
     print(f"{name:42s}: {ms:7.3f} ms per call | {k} probes: clock median {float(per_probe.median()):.3f} GHz, min {float(per_probe.min()):.3f}, "
-          f"max {float(per_probe.max()):.3f}, 10th pct {float(per_probe.quantile(0.1)):.3f} | probe wall {float(us.median()):.0f} us "
-          f"(min {float(us.min()):.0f}, max {float(us.max()):.0f}) | per-XCD spread in one probe {float((ghz.max(dim=1).values - ghz.min(dim=1).values).median()):.3f}",
-          flush=True)
+          f"max {float(per_probe.max()):.3f} | first quarter {float(per_probe[:q].median()):.3f}, last quarter {float(per_probe[-q:].median()):.3f} | "
+          f"medians of the eight eighths of the run: {series}", flush=True)
 
 
 run("idle (probe only)", lambda: None, 40, 1)
 run(f"pipelined training step, group {G}", lambda: st.step(*b), STEPS, 2)
-run("encoder graph alone, back to back", lambda: st.g_encs[0].replay(), 24, 1)
+run("encoder graph alone, back to back", lambda: st.g_encs[0].replay(), max(24, STEPS // 8), 1)
 
 
 def head():
@@ -65,4 +74,4 @@ def head():
 
 
 run("head + AdamW graphs alone, back to back", head, STEPS, 2)
-run(f"pipelined training step, group {G} (again)", lambda: st.step(*b), STEPS, 2)
+run(f"pipelined training step, group {G} (again)", lambda: st.step(*b), 2 * STEPS, 2)
