@@ -447,9 +447,9 @@ def main():
                     shader_clock_ghz_per_profiled_pass=(clock_per_pass if pipeline else None),
                     mfma_pipe_utilisation_at_that_clock=(round(nprod * achieved / (PEAK_BF16_TFLOPS * clock_ghz / 2.4), 4) if clock_ghz else None),
                     clock_note=("shader clock seen by dependent-FMA probe waves started with each profiled encoder pass (delta s_memtime / delta "
-                                "s_memrealtime, ser_debug_clock_probe): the timed schedule holds ~2.4 GHz (scripts/clock_under_load.py: 2.40 GHz "
-                                "median over the pipelined step, 2.0 GHz for encoder passes alone back to back, 1.6 GHz beside a saturating "
-                                "synthetic GEMM), so `peak` (the 2.4 GHz figure) is the right denominator here"),
+                                "s_memrealtime, ser_debug_clock_probe).  MFMA-dense phases pull the clock down: encoder passes alone hold "
+                                "1.73 GHz, the timed schedule (GEMM waves sharing CUs with the head's kernels) 2.36 GHz median "
+                                "(scripts/clock_under_load.py, profiles/r03_c_clock_under_load.txt); `peak` is the 2.4 GHz figure"),
                     kernel=("gemm_x3_kernel / gemm_x3_group_kernel / gemm_f32_kernel (csrc/gemm_f32.hip: fp32 operands split to bf16 hi+lo on the fly; "
                             "forward, dgrad and wgrad products of encoders and head)" if args.unfreeze else
                             "gemm_bf16_nt_kernel + gemm_bf16_pair_kernel (same tile code; the pair form runs layer l of both encoders)"),
