@@ -19,7 +19,12 @@ python scripts/pmc_traffic.py gpurun_out/${TAG}_pmc_f/f_counter_collection.csv g
 cat gpurun_out/${TAG}_pmc_traffic.json | head -40
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 --front-end > gpurun_out/${TAG}_bench_front_end.json 2> gpurun_out/${TAG}_bench_front_end.err; echo "front-end rc=$?"
 cut -c1-300 gpurun_out/${TAG}_bench_front_end.json
-timeout -k 10 400 python bench.py --unfreeze --batch 8 --steps 6 --warmup 2 > gpurun_out/${TAG}_bench_config3_full_finetune.json 2> gpurun_out/${TAG}_bench_config3.err; echo "config3 rc=$?"
+timeout -k 10 400 python bench.py --unfreeze --batch 8 --steps 12 --warmup 3 > gpurun_out/${TAG}_bench_config3_full_finetune.json 2> gpurun_out/${TAG}_bench_config3.err; echo "config3 rc=$?"
 cut -c1-400 gpurun_out/${TAG}_bench_config3_full_finetune.json
+timeout -k 10 300 python bench.py --unfreeze --batch 8 --steps 12 --warmup 3 --precision bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_config3_amp.json 2> gpurun_out/${TAG}_bench_config3_amp.err; echo "config3 amp rc=$?"
+cut -c1-400 gpurun_out/${TAG}_bench_config3_amp.json
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${TAG}_c3prof -o k -- python3 scripts/finetune_steps.py bf16 12 graph > /dev/null 2> gpurun_out/${TAG}_c3prof.err; echo "config3 prof rc=$?"
+python scripts/burst_summary.py gpurun_out/${TAG}_c3prof/k_kernel_trace.csv 8 > gpurun_out/${TAG}_config3_amp_kernel_summary.md 2>&1
+rm -rf gpurun_out/${TAG}_c3prof
 rm -rf gpurun_out/${TAG}_pmc_f gpurun_out/${TAG}_pmc_w gpurun_out/${TAG}_prof/k_kernel_trace.csv
 head -30 gpurun_out/${TAG}_summary.md
