@@ -50,15 +50,27 @@ SER_DEVFN void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// [rows16][HD + 4] <- x[(b S + pos) ld + h HD + d], zero rows for pos >= S
+// [rows16][HD + 4] <- x[(b S + pos) ld + h HD + d], zero rows for pos >= S.  Eight loads are in flight per thread before the
+// first LDS store: a plain load / store loop pays one memory round trip per iteration (the kernel is latency-bound here, with
+// one workgroup per CU).
 template <int HD>
 SER_DEVFN void stage_rows(float* __restrict__ dst, const float* __restrict__ x, int ld, int b, int h, int S, int S16) {
-  constexpr int C4 = HD / 4, PK = HD + 4;
-  for (int idx = threadIdx.x; idx < S16 * C4; idx += 256) {
-    const int pos = idx / C4, c = idx % C4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pos < S) v = *(const float4*)(x + ((long long)b * S + pos) * ld + h * HD + c * 4);
-    *(float4*)(dst + pos * PK + c * 4) = v;
+  constexpr int C4 = HD / 4, PK = HD + 4, U = 8;
+  const int n = S16 * C4;
+  for (int base = threadIdx.x; base < n; base += 256 * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256;
+      const int pos = idx / C4, c = idx % C4;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < n && pos < S) v[u] = *(const float4*)(x + ((long long)b * S + pos) * ld + h * HD + c * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * 256;
+      if (idx < n) *(float4*)(dst + (idx / C4) * PK + (idx % C4) * 4) = v[u];
+    }
   }
 }
 
@@ -258,9 +270,22 @@ __global__ __launch_bounds__(256) void xattn_bwd_kv_mfma_kernel(const float* __r
   for (int phase = 0; phase < 2; ++phase) {
     const float* panel = phase == 0 ? dS : Pv;
     if (phase) __syncthreads();
-    for (int idx = tid; idx < Sq16 * 64; idx += 256) {
-      const int i = idx >> 6, c = idx & 63;
-      St[i * PS + c] = (i < Sq && key0 + c < Sk) ? panel[(prow0 + i) * Sk + key0 + c] : 0.f;
+    {                                                  // 16 loads in flight per thread (see stage_rows)
+      constexpr int U = 16;
+      const int n = Sq16 * 64;
+      for (int base = tid; base < n; base += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * 256, i = idx >> 6, c = idx & 63;
+          v[u] = (idx < n && i < Sq && key0 + c < Sk) ? panel[(prow0 + i) * Sk + key0 + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * 256;
+          if (idx < n) St[(idx >> 6) * PS + (idx & 63)] = v[u];
+        }
+      }
     }
     stage_rows<HD>(Xs, phase == 0 ? q : dctx, phase == 0 ? ldq : ldc, b, h, Sq, Sq16);
     __syncthreads();

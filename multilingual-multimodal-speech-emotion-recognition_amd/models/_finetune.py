@@ -527,9 +527,12 @@ class _PosConv(torch.autograd.Function):
         db = torch.empty(H, dtype=torch.float32, device=dout.device)
         dslabs = torch.empty_like(slabs) if ctx.needs_input_grad[0] else None
         np_ = L.lib.ser_get_head_backward_products()
+        # the bias reaches every output frame once: its gradient is the column sum of dout itself (one two-stage sum for all groups)
+        dout = dout.contiguous()
+        ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(H)), dtype=torch.uint8, device=dout.device)
+        L.check(L.lib.ser_colsum_tall(L.ptr(dout), B * S, H, H, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
         for g in range(G):
             _gemm(dy[g].data_ptr(), 1, Cg, slabs[g].data_ptr(), Cg, 1, Cg, K * Cg, rows, dW2[g * Cg:].data_ptr(), K * Cg, products=np_)
-            L.check(L.lib.ser_colsum(dy[g].data_ptr(), rows, Cg, Cg, db[g * Cg:].data_ptr(), 0, L.stream_ptr()), "ser_colsum")
         if dslabs is not None:
             dwin = torch.empty(rows, K * Cg, dtype=torch.float32, device=dout.device)
             for g in range(G):
