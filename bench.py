@@ -395,6 +395,8 @@ def main():
         if pipeline:
             stepper.profile_encoder_passes(4)          # un-profiled: brings the chip to the clock it holds under this load
         L.check(prof_start())
+        if args.unfreeze:                              # the fine-tuning step runs both GEMM families: the encoders' tile kernel too
+            L.check(L.lib.ser_prof_gemm_start())
         if pipeline:
             # the launches the timed region replays from its graphs - one encoder pass over `group` batches - issued eagerly
             # on the encoder stream with a HIP event pair around every GEMM launch, BESIDE head-graph replays on the main
@@ -411,6 +413,11 @@ def main():
         ms, fl, n = C.c_double(), C.c_double(), C.c_longlong()
         prof_stop.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         L.check(prof_stop(C.byref(ms), C.byref(fl), C.byref(n)))
+        if args.unfreeze:
+            ms2, fl2, n2 = C.c_double(), C.c_double(), C.c_longlong()
+            L.lib.ser_prof_gemm_stop.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+            L.check(L.lib.ser_prof_gemm_stop(C.byref(ms2), C.byref(fl2), C.byref(n2)))
+            ms.value, fl.value, n.value = ms.value + ms2.value, fl.value + fl2.value, n.value + n2.value
         achieved = fl.value / (ms.value * 1e-3) / 1e12
         # HBM-side bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE, separate --pmc runs; see profiles/): bench.py cannot run the profiler itself
@@ -422,6 +429,8 @@ def main():
             tr_fetch, tr_write = round(rec["fetch_bytes_per_launch_corrected"]), round(rec["write_bytes_per_launch"])
         except Exception:  # noqa: BLE001
             traffic = None
+        if args.unfreeze:                              # the committed PMC passes cover the frozen configuration's launches only
+            traffic = tr_fetch = tr_write = None
         if pipeline and args.precision == "bf16x3" and not args.stress:
             # algorithmic operand / result bytes per launch of one grouped encoder pass (split-bf16 planes: 4 B per element
             # in, 4 B out; the residual of the two N = hidden layer GEMMs is read once): what `traffic` is compared with
@@ -450,8 +459,9 @@ def main():
                                 "s_memrealtime, ser_debug_clock_probe).  MFMA-dense phases pull the clock down: encoder passes alone hold "
                                 "1.73 GHz, the timed schedule (GEMM waves sharing CUs with the head's kernels) 2.36 GHz median "
                                 "(scripts/clock_under_load.py, profiles/r03_c_clock_under_load.txt); `peak` is the 2.4 GHz figure"),
-                    kernel=("gemm_x3_kernel / gemm_x3_group_kernel / gemm_f32_kernel (csrc/gemm_f32.hip: fp32 operands split to bf16 hi+lo on the fly; "
-                            "forward, dgrad and wgrad products of encoders and head)" if args.unfreeze else
+                    kernel=("gemm_bf16_nt_kernel (csrc/gemm_bf16.hip: the encoders' Linear and conv layers through split planes - forward, dgrad, "
+                            "wgrad) + gemm_x3_kernel / gemm_x3_group_kernel / gemm_f32_kernel (csrc/gemm_f32.hip: operands split on the fly; "
+                            "positional conv, conv0, head); all launches of an eager step timed" if args.unfreeze else
                             "gemm_bf16_nt_kernel + gemm_bf16_pair_kernel (same tile code; the pair form runs layer l of both encoders)"),
                     launches_per_step=round(n.value / steps_profiled, 2),
                     launches_per_encoder_pass=n.value // nprof,

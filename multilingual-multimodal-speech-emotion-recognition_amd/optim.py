@@ -77,20 +77,24 @@ class FlatAdamW:
         for pg, g in zip(self.param_groups, self.groups):
             pg["lr"] = self.base_lr * self.lr_factor * g["lr_mult"]
 
-    def launch(self):
-        """Device side of a step (capturable)."""
+    def launch(self, only=None, skip=None):
+        """Device side of a step (capturable).  only / skip: sets of id(parameter) among the parameters outside the flat buckets -
+        `only` updates just those (the early update of an encoder whose backward is complete, TrainStepper), `skip` leaves them
+        out of the regular launch."""
         if self._plan is None:
             self._build_plan()
         b1, b2 = self.betas
         segs_all = []                                   # (p, g, m, v, lr_mult, weight_decay) of every live segment
         for grp, segs, loose in self._plan:
             for b, s, e in segs:
+                if only is not None:
+                    break
                 if b.params[0].grad is None and all(p.grad is None for p in b.params):
                     continue
                 m, v = self._mv(id(b), b.flat)
                 segs_all.append((b.flat[s:e], b.gflat[s:e], m[s:e], v[s:e], grp["lr_mult"], grp["weight_decay"]))
             for p in loose:
-                if p.grad is None:
+                if p.grad is None or (only is not None and id(p) not in only) or (skip is not None and id(p) in skip):
                     continue
                 m, v = self._mv(id(p), p.data)
                 segs_all.append((p.data, p.grad.contiguous(), m, v, grp["lr_mult"], grp["weight_decay"], self.gates.get(id(p))))
