@@ -668,7 +668,9 @@ class TrainStepper:
         for _, n in noises:
             n.static = True
         self.sys.stage_encoder_noise(wave.shape, ids.shape, dev)
-        self.opt.set_gates(self.sys.layerdrop_gates())            # before the optimizer launch is captured
+        # before the optimizer launch is captured; not under data parallelism: ranks drop different layers, every replica applies
+        # the reduced gradient (a rank's zero contribution included)
+        self.opt.set_gates(self.sys.layerdrop_gates() if self.reducer is None else {})
         try:
             self._capture_body(wave, ids, mask, labels, lid)
         finally:

@@ -155,8 +155,10 @@ class HipEngine:
         self.opt = self.sys.make_optimizer(lr=args.lr)
         self.sched = WarmupCosine(self.opt, steps_per_epoch * args.epochs, args.warmup_ratio)
         self.reducer = GradReducer(self.sys) if world > 1 else None
-        # LayerDrop / SpecAugment are per-step host decisions: no graph
-        self.stepper = TrainStepper(self.sys, self.opt, self.sched, self.reducer, use_graph=args.graph and not noisy,
+        # LayerDrop / SpecAugment are per-step host decisions: a captured step takes them as device words staged before each replay
+        # (models/_finetune.py Noise.stage; a dropped layer's AdamW update is gated by the same word).  Under data parallelism the
+        # ranks drop different layers and the reduced gradient decides, so that combination steps eagerly
+        self.stepper = TrainStepper(self.sys, self.opt, self.sched, self.reducer, use_graph=args.graph and (not noisy or world == 1),
                                     use_proto=args.proto_weight > 0)
         self.aug = AugmentRng(args.seed, rank) if args.augment else None
         self.start_epoch = 0
@@ -194,6 +196,9 @@ class HipEngine:
             # ragged clips: the reference's pad-to-longest semantics (one encoder pass per distinct length), eager launches
             audio_list = self.aug.host(audio_list)
         self.opt.zero_grad(set_to_none=True)
+        for _, n in s.encoder_noises():          # eager forward: LayerDrop / SpecAugment act as host decisions (a captured step left the
+            n.static = False                     # device-word mode on), and a dropped layer's parameters simply have no gradient
+        gates, self.opt.gates = self.opt.gates, {}
         if self.reducer:
             self.reducer.arm(overlap=False)      # one adapter backward per clip length: buckets are complete only after backward
         a_seq, a_mask = s.audio_encoder(audio_list, text_list)
@@ -207,6 +212,7 @@ class HipEngine:
         if self.reducer:
             self.reducer.finish()
         self.opt.step()
+        self.opt.gates = gates
         self.sched.step()
         return loss.detach()
 

@@ -113,3 +113,29 @@ def test_train_and_eval_cli_with_the_reference_default_front_end(tmp_path, capsy
         assert "Weighted F1 Score" in capsys.readouterr().out
     finally:
         os.chdir(cwd)
+
+
+def test_train_cli_full_fine_tune_with_amp_and_graphs(tmp_path):
+    """BASELINE config 3 through the command line: --unfreeze_encoders --use_amp --graph (encoders' training-mode noise on, as the
+    reference's .train() leaves it: LayerDrop / SpecAugment decisions are staged as device words before each captured step), one
+    epoch over equal-length and ragged batches; the encoder weights in the checkpoint have moved."""
+    import ser_amd  # noqa: F401
+    from ser_amd import train as ser_train
+    tmp = str(tmp_path)
+    da, dt = _local_models(tmp)
+    tr, va = _manifests(tmp, n_train=8, n_val=4)
+    from transformers import Wav2Vec2Model
+    w0 = Wav2Vec2Model.from_pretrained(da).state_dict()["encoder.layers.0.attention.q_proj.weight"].clone()
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        f1 = ser_train.main(["--train_manifest", tr, "--val_manifest", va, "--epochs", "1", "--batch_size", "2",
+                             "--save_dir", os.path.join(tmp, "ck"), "--audio_model", da, "--text_model", dt,
+                             "--warmup_ratio", "0.0", "--unfreeze_encoders", "--use_amp", "--graph"])
+        cks = sorted(os.listdir(os.path.join(tmp, "ck")))
+        assert len(cks) == 1 and 0.0 <= f1 <= 1.0
+        ck = torch.load(os.path.join(tmp, "ck", cks[0]), map_location="cpu", weights_only=False)
+        w1 = ck["audio_encoder"]["encoder.encoder.layers.0.attention.q_proj.weight"]
+        assert torch.isfinite(w1).all() and (w1 - w0).abs().max().item() > 0.0, "the encoders are trained"
+    finally:
+        os.chdir(cwd)
