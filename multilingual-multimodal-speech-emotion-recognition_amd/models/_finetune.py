@@ -3,13 +3,21 @@
 Wav2Vec2 / XLM-R parameter receives a gradient.
 
 The frozen path (csrc/encoders.hip) keeps the encoders as packed split-bf16 planes and has no backward.  This path runs
-the same arithmetic in fp32 tensors through the operators of the trainable head — every matrix product is
-`ser_gemm_f32` (fp32 in / out, three bf16 MFMA products per multiply with the operands split on the fly, any strides:
-which makes a Conv1d a GEMM over a strided window view, its input gradient one accumulating GEMM per tap, and its weight
-gradient a GEMM over the same view), LayerNorm / attention are the head's `ser_layernorm_fwd,bwd` / `ser_xattn_fwd,bwd`, and
-csrc/finetune.hip adds the pieces the head never needed (GELU backward, GroupNorm over time, the positional conv's
-overlap-add, embedding gather / scatter-add).  torch is the autograd tape and the view / permute plumbing; the one place
-torch arithmetic is used is the weight-norm of the positional conv's 4.7 M-element weight (g * v / ||v||, a parameter
+the same arithmetic on fp32 tensors with torch as the autograd tape and the view / permute plumbing:
+  * encoder-sized Linear layers and the 512-channel conv layers run forward, input-gradient and weight-gradient products on the
+    frozen encoders' MFMA tile kernel (`ser_gemm_bf16_nt`) through split operand planes - straight and transposed from ONE pass
+    per operand (`ser_split_bf16_both`), the conv's window view read straight out of the planes of its input, its input gradient
+    folded back from per-window gradients by a gather (`ser_conv_col2im`);
+  * what does not fit the tile kernel (conv0 with one input channel, the 16-group positional conv with 48 channels per group,
+    small test shapes) is `ser_gemm_f32` (fp32 in / out, operands split on the fly, any strides: a Conv1d is a GEMM over a
+    strided window view);
+  * attention is the head's `ser_xattn_fwd,bwd` on the fused q | k | v buffer (fp32 matrix pipe, csrc/xattn_mfma.hip); LayerNorm,
+    GELU and the dropout sites are the head's kernels, fused where they follow each other (dropout + residual + LayerNorm, GELU +
+    dropout); csrc/finetune.hip adds the pieces the head never needed (GELU backward, GroupNorm over time, the positional conv's
+    overlap-add, embedding gather / owner-computes scatter-add);
+  * products per multiply: 3 (fp32-equivalent) or, in the `bf16` precision mode (train.py --use_amp), 1;
+  * the step is capturable: LayerDrop / SpecAugment decisions can be staged as device words (`Noise.stage`).
+The one place torch arithmetic is used is the weight-norm of the positional conv's 4.7 M-element weight (g * v / ||v||, a parameter
 transform, hf modeling_wav2vec2.py:326-349).
 
 Semantics: eval-mode HuggingFace forward (no encoder dropout / SpecAugment / LayerDrop), i.e. what the golden gradients
@@ -408,31 +416,10 @@ class _ColNorm(torch.autograd.Function):
         return dx, dg, db, None, None, None, None
 
 
-class _Attention(torch.autograd.Function):
-    """softmax(q k^T / sqrt(d) + key mask) v per head on [B*S, H] operands: the head's attention kernels
-    (hf wav2vec2 :438-463, xlm_roberta :211-250)."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, key_mask, B, S, heads, drop, site):
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out, P = O.xattn_fwd(q, k, v, key_mask, B, S, S, heads, drop, site)
-        ctx.P = P                                     # the softmax output, or (softmax, dropped) under dropout
-        ctx.save_for_backward(q, k, v)
-        ctx.dims = (B, S, heads, drop, site)
-        return out
-
-    @staticmethod
-    def backward(ctx, dctx):
-        q, k, v = ctx.saved_tensors
-        B, S, heads, drop, site = ctx.dims
-        dq, dk, dv = O.xattn_bwd(dctx.contiguous(), q, k, v, ctx.P, B, S, S, heads, drop, site)
-        return dq, dk, dv, None, None, None, None, None, None
-
-
 class _AttentionQKV(torch.autograd.Function):
-    """The same attention on the fused projection output qkv [B*S, 3 H] (q | k | v column blocks): the kernels read the blocks
-    through their row stride and backward writes dq | dk | dv into one [B*S, 3 H] gradient - no slice copies going in and no
-    zero-fill + copy + add per block coming back."""
+    """softmax(q k^T / sqrt(d) + key mask) v per head (hf wav2vec2 :438-463, xlm_roberta :211-250) on the fused projection output
+    qkv [B*S, 3 H] (q | k | v column blocks): the head's attention kernels read the blocks through their row stride and backward
+    writes dq | dk | dv into one [B*S, 3 H] gradient - no slice copies going in and no zero-fill + copy + add per block coming back."""
 
     @staticmethod
     def forward(ctx, qkv, key_mask, B, S, heads, drop, site):
@@ -455,43 +442,12 @@ class _AttentionQKV(torch.autograd.Function):
         return d, None, None, None, None, None, None
 
 
-class _Toeplitz(torch.autograd.Function):
-    """One group of the positional conv for all clips at once.  slab [B*R + K, Cg]: per clip R = S + K - 1 zero-padded
-    rows, clips back to back (+ K rows of slack), so the window rows of every clip are ONE strided view with row step Cg:
-    out[m] = slab[m : m + K].flatten() . W2^T for m in [0, B*R) — the rows m = b R + t, t >= S, straddle two clips and are
-    never used (their upstream gradient is zero)."""
-
-    @staticmethod
-    def forward(ctx, slab, W2, bias, rows, K):
-        Cg = slab.shape[1]
-        N = W2.shape[0]
-        y = torch.empty(rows, N, dtype=torch.float32, device=slab.device)
-        _gemm(slab.data_ptr(), Cg, 1, W2.data_ptr(), 1, K * Cg, rows, N, K * Cg, y, N, bias=bias)
-        ctx.save_for_backward(slab, W2)
-        ctx.rows, ctx.K = rows, K
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        slab, W2 = ctx.saved_tensors
-        rows, K = ctx.rows, ctx.K
-        Cg, N = slab.shape[1], W2.shape[0]
-        dy = dy.contiguous()
-        dW2 = torch.empty_like(W2)
-        _gemm(dy.data_ptr(), 1, N, slab.data_ptr(), Cg, 1, N, K * Cg, rows, dW2, K * Cg)
-        db = torch.empty(N, dtype=torch.float32, device=dy.device)
-        L.check(L.lib.ser_colsum(L.ptr(dy), rows, N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
-        dslab = None
-        if ctx.needs_input_grad[0]:
-            dwin = O.linear_dgrad(dy, W2)                               # [rows, K*Cg]
-            dslab = torch.empty_like(slab)
-            L.check(L.lib.ser_toeplitz_add(L.ptr(dwin), rows, K, Cg, slab.shape[0], L.ptr(dslab), L.stream_ptr()), "ser_toeplitz_add")
-        return dslab, dW2, db, None, None
-
-
 class _PosConv(torch.autograd.Function):
     """The whole positional conv (hf :326-368: grouped Conv1d, kernel K, padding K // 2, last frame dropped when K is even) on
-    z [B*S, H] with the weight-normed weight Wp [H, Cg, K]: every group is the window-view product of `_Toeplitz`, but the zero
+    z [B*S, H] with the weight-normed weight Wp [H, Cg, K].  One group = one product over a window view: its slab [B*R + K, Cg] holds
+    per clip R = S + K - 1 zero-padded rows, clips back to back (+ K rows of slack), so the window rows of every clip are ONE strided
+    view with row step Cg, out[m] = slab[m : m + K].flatten() . W2^T for m in [0, B*R) - the rows m = b R + t, t >= S, straddle two
+    clips and are never used (their upstream gradient is zero).  The zero
     padding, the group split of z and of the weight, and the reassembly of the output happen ONCE for all groups (a padded
     [G, B*R + K, Cg] slab buffer, one [H, K*Cg] weight matrix, one [G, B*R, Cg] output), in forward and in backward, instead of a
     pad / cat / slice chain per group on the autograd tape.  Products per multiply follow the Linear layers' setting."""
