@@ -477,25 +477,30 @@ class _PosConv(torch.autograd.Function):
         H = W2.shape[0]
         Cg, R = H // G, S + K - 1
         rows = B * R
-        dy = torch.zeros(G, rows, Cg, dtype=torch.float32, device=dout.device)   # rows t >= S of a clip straddle two clips: no gradient
-        dy.view(G, B, R, Cg)[:, :, :S] = dout.reshape(B, S, G, Cg).permute(2, 0, 1, 3)
+        dout = dout.contiguous()
+        # dy of group g = rows K-1 .. K-1+rows of a buffer with K-1 zero rows in front and K+1 behind: the input gradient is then
+        # the SAME window-view product as forward, over this buffer with the taps reversed and the channel roles swapped -
+        # dslab[r, ci] = sum_{k', co} dyp[r + k', co] Wt[ci, k' Cg + co], Wt[ci, k', co] = W2[co, K-1-k', ci] - one GEMM per group
+        # instead of a [rows, K Cg] buffer of per-window gradients and an overlap-add pass.  Rows t >= S of a clip straddle two
+        # clips in forward: no gradient.
+        dyp = torch.zeros(G, rows + 2 * K, Cg, dtype=torch.float32, device=dout.device)
+        dyp[:, K - 1:K - 1 + rows].view(G, B, R, Cg)[:, :, :S] = dout.view(B, S, G, Cg).permute(2, 0, 1, 3)
         dW2 = torch.empty_like(W2)
         db = torch.empty(H, dtype=torch.float32, device=dout.device)
-        dslabs = torch.empty_like(slabs) if ctx.needs_input_grad[0] else None
-        np_ = L.lib.ser_get_head_backward_products()
         # the bias reaches every output frame once: its gradient is the column sum of dout itself (one two-stage sum for all groups)
-        dout = dout.contiguous()
         ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(H)), dtype=torch.uint8, device=dout.device)
         L.check(L.lib.ser_colsum_tall(L.ptr(dout), B * S, H, H, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
+        np_ = L.lib.ser_get_head_backward_products()
+        esz = 4 * Cg                                                           # bytes per row
         for g in range(G):
-            _gemm(dy[g].data_ptr(), 1, Cg, slabs[g].data_ptr(), Cg, 1, Cg, K * Cg, rows, dW2[g * Cg:].data_ptr(), K * Cg, products=np_)
-        if dslabs is not None:
-            dwin = torch.empty(rows, K * Cg, dtype=torch.float32, device=dout.device)
-            for g in range(G):
-                O.linear_dgrad(dy[g], W2[g * Cg:(g + 1) * Cg], out=dwin)          # [rows, K*Cg]
-                L.check(L.lib.ser_toeplitz_add(L.ptr(dwin), rows, K, Cg, rows + K, dslabs[g].data_ptr(), L.stream_ptr()), "ser_toeplitz_add")
+            dy_g = dyp[g].data_ptr() + (K - 1) * esz
+            _gemm(dy_g, 1, Cg, slabs[g].data_ptr(), Cg, 1, Cg, K * Cg, rows, dW2[g * Cg:].data_ptr(), K * Cg, products=np_)
         dz = None
-        if dslabs is not None:
+        if ctx.needs_input_grad[0]:
+            Wt = W2.view(G, Cg, K, Cg).flip(2).permute(0, 3, 2, 1).contiguous()   # [G, ci, k', co]
+            dslabs = torch.empty(G, rows + K, Cg, dtype=torch.float32, device=dout.device)
+            for g in range(G):
+                _gemm(dyp[g].data_ptr(), Cg, 1, Wt[g].data_ptr(), 1, K * Cg, rows + K, Cg, K * Cg, dslabs[g].data_ptr(), Cg, products=np_)
             dz = dslabs[:, :rows].view(G, B, R, Cg)[:, :, K // 2:K // 2 + S].permute(1, 2, 0, 3).reshape(B * S, H)
         return dz, dW2.view(H, K, Cg).permute(0, 2, 1), db, None, None, None, None
 
