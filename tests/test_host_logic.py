@@ -265,3 +265,38 @@ def test_reference_checkpoint_round_trip(tmp_path):
     q = sysm.cross.q_a.weight
     assert torch.allclose(topt.state[q]["exp_avg"], ck["_probe"]["cross.q_a.weight"]["exp_avg"])
     assert float(topt.state[q]["step"]) == 2.0
+
+
+def test_encoder_noise_plan_is_the_same_whether_the_forward_or_the_graph_owner_draws_it():
+    """models/_finetune.py Noise: LayerDrop / SpecAugment decisions are host draws.  The eager forward calls plan() itself; a captured
+    step has its owner call plan() + stage() before each replay.  Same generator, same order -> same decisions; a saved / restored
+    generator state replays them (what the capture's warm-up passes rely on); the frame count used to plan ahead of the forward is the
+    conv stack's (hf modeling_wav2vec2.py:1113-1130)."""
+    from transformers import Wav2Vec2Config, Wav2Vec2Model
+    from ser_amd.models._finetune import Noise, wav2vec2_frames
+    cfg = Wav2Vec2Config(hidden_size=64, num_hidden_layers=6, num_attention_heads=2, intermediate_size=128, conv_dim=[32] * 7,
+                         num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=4, layerdrop=0.3, mask_time_prob=0.2,
+                         mask_time_length=3, mask_time_min_masks=2)
+    model = Wav2Vec2Model(cfg)
+    for T in (4000, 16000, 64000, 12345):
+        assert wav2vec2_frames(cfg, T) == int(model._get_feat_extract_output_lengths(T))
+    a, b = Noise(cfg, 0, seed=9), Noise(cfg, 0, seed=9)
+    seq_a, seq_b = [], []
+    for step in range(6):
+        S = wav2vec2_frames(cfg, 16000)
+        a.plan(cfg.num_hidden_layers, 3, S)
+        seq_a.append((sorted(a.skip), a.spec_mask.copy()))
+        if step == 2:                                  # a capture in the middle of a run: draws made for warm-up are put back
+            st = b.state()
+            for _ in range(3):
+                b.plan(cfg.num_hidden_layers, 3, S)
+            b.set_state(st)
+        b.plan(cfg.num_hidden_layers, 3, S)
+        seq_b.append((sorted(b.skip), b.spec_mask.copy()))
+    assert any(s for s, _ in seq_a), "the draws must drop some layer"
+    for (sa, ma), (sb, mb) in zip(seq_a, seq_b):
+        assert sa == sb and (ma == mb).all()
+        assert ma.shape == (3, wav2vec2_frames(cfg, 16000)) and ma.any()
+    t = Noise(cfg, 1, seed=9)                          # the text encoder: hidden / attention dropout only, no host decisions
+    t.plan(4, 3, 32)
+    assert not t.skip and t.spec_mask is None
