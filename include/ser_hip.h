@@ -71,6 +71,11 @@ int ser_split_bf16_t(const float* x, int R, int C, long long ldx, uint16_t* hi, 
  * product reads x and W straight and whose backward products read them (and dy) transposed. */
 int ser_split_bf16_both(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi, uint16_t* t_lo,
                         int Rp, void* stream);
+/* ... and, in the same pass, the column sums of every block of 32 rows: colpart[Rp / 32][C] (rows added in increasing order).
+ * ser_colsum over colpart (M = Rp / 32) finishes the column sum of x - the bias gradient of a Linear layer whose dy is being
+ * split anyway - in a fixed order, without another pass over x. */
+int ser_split_bf16_both_colsum(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
+                               uint16_t* t_lo, int Rp, float* colpart, void* stream);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, split-bf16 operands, fp32 accumulate.
  * Replaces every torch.nn.Linear / Conv1d-as-GEMM inside the frozen encoders

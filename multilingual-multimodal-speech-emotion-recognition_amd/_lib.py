@@ -163,7 +163,10 @@ def split_bf16_t(x, want_lo=True, pad=64, out=None):
 _sig("ser_split_bf16_both", i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp)
 
 
-def split_bf16_both(x, straight_lo=True, t_lo=True, pad=64):
+_sig("ser_split_bf16_both_colsum", i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp)
+
+
+def split_bf16_both(x, straight_lo=True, t_lo=True, pad=64, colpart=False):
     """fp32 [R, C] contiguous-row device tensor (C % 32 == 0) -> (planes of x, planes of x^T, Rp) in one pass: each either ONE
     interleaved bf16 tensor ([R, 2 C] / [C, 2 Rp]) or, with its `lo` flag off, the hi plane alone ([R, C] / [C, Rp])."""
     assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % IL_GROUP == 0
@@ -171,6 +174,12 @@ def split_bf16_both(x, straight_lo=True, t_lo=True, pad=64):
     Rp = (R + pad - 1) // pad * pad
     s = torch.empty(R, (2 if straight_lo else 1) * Cc, dtype=torch.bfloat16, device=x.device)
     t = torch.empty(Cc, (2 if t_lo else 1) * Rp, dtype=torch.bfloat16, device=x.device)
+    if colpart:           # + column sums per block of 32 rows: [Rp / 32, C] (finish with ser_colsum)
+        part = torch.empty(Rp // 32, Cc, dtype=torch.float32, device=x.device)
+        check(lib.ser_split_bf16_both_colsum(x.data_ptr(), R, Cc, x.stride(0), s.data_ptr(), s.data_ptr() + 2 * IL_GROUP if straight_lo else None,
+                                             t.data_ptr(), t.data_ptr() + 2 * IL_GROUP if t_lo else None, Rp, part.data_ptr(), stream_ptr()),
+              "ser_split_bf16_both_colsum")
+        return s, t, Rp, part
     check(lib.ser_split_bf16_both(x.data_ptr(), R, Cc, x.stride(0), s.data_ptr(), s.data_ptr() + 2 * IL_GROUP if straight_lo else None,
                                   t.data_ptr(), t.data_ptr() + 2 * IL_GROUP if t_lo else None, Rp, stream_ptr()), "ser_split_bf16_both")
     return s, t, Rp

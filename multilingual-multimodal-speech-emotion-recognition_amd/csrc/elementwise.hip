@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void split_t_kernel(const float* __restrict__ 
 // its forward product and transposed in its backward products (and dy both ways in backward): one launch instead of two each.
 __global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict__ x, int R, int C, long long ldx, bf16_t* __restrict__ s_hi,
                                                          bf16_t* __restrict__ s_lo, bf16_t* __restrict__ t_hi, bf16_t* __restrict__ t_lo,
-                                                         int Rp) {
+                                                         int Rp, float* __restrict__ colpart) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -134,6 +134,14 @@ __global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict
     }
   }
   __syncthreads();
+  // column sums of this block's 32 rows (rows >= R are zeros), rows added in increasing order: colpart[blockIdx.x][c] - the
+  // first stage of a bias gradient (x = dy of a Linear layer) at no extra pass over x
+  if (colpart != nullptr && ty == 0 && c0 + tx < C) {
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) a += tile[r][tx];
+    colpart[(long long)blockIdx.x * C + c0 + tx] = a;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i;
@@ -149,6 +157,17 @@ __global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict
     }
   }
 }
+extern "C" int ser_split_bf16_both_colsum(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
+                                          uint16_t* t_lo, int Rp, float* colpart, void* stream) {
+  SER_REQUIRE(x && s_hi && t_hi && R > 0 && C > 0 && C % SER_IL_GROUP == 0 && Rp >= R && Rp % SER_IL_GROUP == 0,
+              "split_bf16_both: bad arguments (R=%d C=%d Rp=%d)", R, C, Rp);
+  SER_REQUIRE((s_lo == nullptr || ser_is_il(s_hi, s_lo)) && (t_lo == nullptr || ser_is_il(t_hi, t_lo)),
+              "split_bf16_both: both planes are written only in the interleaved layout (lo == hi + 32)");
+  hipLaunchKernelGGL(split_both_kernel, dim3(Rp / 32, C / 32), dim3(256), 0, (hipStream_t)stream, x, R, C, ldx, (bf16_t*)s_hi,
+                     (bf16_t*)s_lo, (bf16_t*)t_hi, (bf16_t*)t_lo, Rp, colpart);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
 extern "C" int ser_split_bf16_both(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
                                    uint16_t* t_lo, int Rp, void* stream) {
   SER_REQUIRE(x && s_hi && t_hi && R > 0 && C > 0 && C % SER_IL_GROUP == 0 && Rp >= R && Rp % SER_IL_GROUP == 0,
@@ -156,7 +175,7 @@ extern "C" int ser_split_bf16_both(const float* x, int R, int C, long long ldx, 
   SER_REQUIRE((s_lo == nullptr || ser_is_il(s_hi, s_lo)) && (t_lo == nullptr || ser_is_il(t_hi, t_lo)),
               "split_bf16_both: both planes are written only in the interleaved layout (lo == hi + 32)");
   hipLaunchKernelGGL(split_both_kernel, dim3(Rp / 32, C / 32), dim3(256), 0, (hipStream_t)stream, x, R, C, ldx, (bf16_t*)s_hi,
-                     (bf16_t*)s_lo, (bf16_t*)t_hi, (bf16_t*)t_lo, Rp);
+                     (bf16_t*)s_lo, (bf16_t*)t_hi, (bf16_t*)t_lo, Rp, (float*)nullptr);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

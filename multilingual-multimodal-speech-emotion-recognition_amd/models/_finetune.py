@@ -158,15 +158,17 @@ class _Linear(torch.autograd.Function):
             xt, Mp, wt, Np, _ = saved
         else:
             (xt, Mp), (wt, Np) = L.split_bf16_t(x, three), L.split_bf16_t(W, three)
-        dys, dyt, Mp2 = L.split_bf16_both(dy, three, three)
+        if db is not None:                                       # the bias gradient's first stage rides on the operand pass over dy
+            dys, dyt, Mp2, part = L.split_bf16_both(dy, three, three, colpart=True)
+        else:
+            dys, dyt, Mp2 = L.split_bf16_both(dy, three, three)
         assert Mp2 == Mp
         dx = torch.empty(M, K, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
-        ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(N)), dtype=torch.uint8, device=dy.device) if db is not None else None
         if dx is not None:                                       # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
             _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
         _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)        # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
-        if db is not None:
-            L.check(L.lib.ser_colsum_tall(L.ptr(dy), M, N, N, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
+        if db is not None:                                       # second stage: the Mp / 32 block sums, in block order
+            L.check(L.lib.ser_colsum(L.ptr(part), part.shape[0], N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
         return dx, dW, db
 
 
