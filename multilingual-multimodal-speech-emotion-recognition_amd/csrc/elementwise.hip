@@ -157,6 +157,70 @@ __global__ __launch_bounds__(256) void split_both_kernel(const float* __restrict
     }
   }
 }
+// The same for MANY matrices in one launch (the weights of every Linear layer of an encoder, once per step): blockIdx.z picks a
+// descriptor of 12 64-bit words {x, s_hi, s_lo, t_hi, t_lo, R, C, Rp, t_roff, ldx, cover, bias_src | bias_dst packed below}.
+// A matrix may be a row block of a vertically fused operand (q | k | v): its straight planes start at its first row (the pointer)
+// and its transposed planes at row offset t_roff of the fused operand's Rp-long rows.  cover = rows to walk (R, or the padded Rp
+// of a stand-alone matrix: the padding is zero-filled).  An optional bias copy (bias_n floats) rides on block (0, 0).
+struct SplitDesc {
+  const float* x; bf16_t* s_hi; bf16_t* s_lo; bf16_t* t_hi; bf16_t* t_lo;
+  long long R, C, Rp, t_roff, ldx, cover;
+  const float* bias_src; float* bias_dst; long long bias_n;
+};
+__global__ __launch_bounds__(256) void split_both_multi_kernel(const SplitDesc* __restrict__ tab) {
+  const SplitDesc d = tab[blockIdx.z];
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && d.bias_src != nullptr)
+    for (int i = threadIdx.x; i < d.bias_n; i += 256) d.bias_dst[i] = d.bias_src[i];
+  if (r0 >= d.cover || c0 >= d.C) return;              // workgroup-uniform
+  const int R = (int)d.R, C = (int)d.C;
+  const bool s_il = d.s_lo != nullptr, t_il = d.t_lo != nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    const bool in = r < R && c < C;
+    const float v = in ? d.x[(long long)r * d.ldx + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (in) {
+      bf16_t h, l;
+      split_bf16(v, h, l);
+      if (s_il) {
+        const long long o = 2 * ((long long)r * C + c0) + tx;
+        d.s_hi[o] = h;
+        d.s_hi[o + SER_IL_GROUP] = l;
+      } else {
+        d.s_hi[(long long)r * C + c] = h;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i;
+    if (c >= C) continue;
+    bf16_t h, l;
+    split_bf16(tile[tx][ty + 8 * i], h, l);
+    if (t_il) {
+      const long long o = (long long)c * 2 * d.Rp + 2 * (d.t_roff + r0) + tx;
+      d.t_hi[o] = h;
+      d.t_hi[o + SER_IL_GROUP] = l;
+    } else {
+      d.t_hi[(long long)c * d.Rp + d.t_roff + r0 + tx] = h;
+    }
+  }
+}
+// table: nprob descriptors of 14 64-bit words each in DEVICE memory (layout of SplitDesc); rblocks / cblocks: the largest
+// cover / 32 and C / 32 among them.  Every C and t_roff must be a multiple of 32, every Rp and cover a multiple of 32.
+extern "C" int ser_split_bf16_both_multi(const void* table, int nprob, int rblocks, int cblocks, void* stream) {
+  SER_REQUIRE(table && nprob > 0 && nprob <= 65535 && rblocks > 0 && cblocks > 0, "split_bf16_both_multi: bad arguments");
+  static_assert(sizeof(SplitDesc) == 14 * 8, "descriptor layout");
+  hipLaunchKernelGGL(split_both_multi_kernel, dim3(rblocks, cblocks, nprob), dim3(256), 0, (hipStream_t)stream, (const SplitDesc*)table);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 extern "C" int ser_split_bf16_both_colsum(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
                                           uint16_t* t_lo, int Rp, float* colpart, void* stream) {
   SER_REQUIRE(x && s_hi && t_hi && R > 0 && C > 0 && C % SER_IL_GROUP == 0 && Rp >= R && Rp % SER_IL_GROUP == 0,

@@ -105,6 +105,76 @@ def _tile_ok(M, N, K):
     return M >= 64 and N % 64 == 0 and K % 64 == 0
 
 
+class WeightPlanes:
+    """Operand planes of MANY weight matrices refreshed by ONE launch per step (`ser_split_bf16_both_multi`): for every entry the
+    planes of W (forward product) and of W^T (input-gradient product) in persistent buffers - instead of a pass per weight inside
+    every Linear's forward, and instead of concatenating q | k | v weights first: an entry may stack several matrices vertically
+    (their planes land in row blocks of one fused operand, their biases in one fused bias vector).
+
+    entries: {key: [(W, b | None), ...]} with all W of an entry [N_i, K] (same K, N_i % 32 == 0 when stacked).  three_f / three_b:
+    interleaved hi / lo planes (three-product mode) for the forward / backward operand.  get(key) -> (ws, wt, Np, bias | None)."""
+
+    def __init__(self, entries, three_f, three_b, device):
+        import numpy as np
+        self.mode = (bool(three_f), bool(three_b))
+        self.out, rows = {}, []
+        self.ptrs = []
+        rb = cb = 1
+        for key, mats in entries.items():
+            K = mats[0][0].shape[1]
+            N = sum(int(W.shape[0]) for W, _ in mats)
+            Np = (N + 63) // 64 * 64
+            ws = torch.empty(N, (2 if three_f else 1) * K, dtype=torch.bfloat16, device=device)
+            wt = torch.zeros(K, (2 if three_b else 1) * Np, dtype=torch.bfloat16, device=device)
+            fused_bias = None
+            if len(mats) > 1 and all(b is not None for _, b in mats):
+                fused_bias = torch.empty(N, dtype=torch.float32, device=device)
+            elif len(mats) == 1:
+                fused_bias = mats[0][1]                         # the parameter itself: no copy
+            r0 = 0
+            for W, b in mats:
+                R = int(W.shape[0])
+                assert W.dim() == 2 and W.shape[1] == K and W.is_contiguous() and K % 32 == 0 and (len(mats) == 1 or R % 32 == 0)
+                cover = Np if len(mats) == 1 else R
+                s_hi = ws.data_ptr() + 2 * r0 * ws.shape[1]
+                copy = len(mats) > 1 and b is not None and fused_bias is not None
+                rows.append([W.data_ptr(), s_hi, s_hi + 2 * L.IL_GROUP if three_f else 0, wt.data_ptr(),
+                             wt.data_ptr() + 2 * L.IL_GROUP if three_b else 0, R, K, Np, r0, K, cover,
+                             b.data_ptr() if copy else 0, fused_bias.data_ptr() + 4 * r0 if copy else 0, R if copy else 0])
+                self.ptrs.append((W, W.data_ptr()))
+                rb, cb = max(rb, cover // 32), max(cb, K // 32)
+                r0 += R
+            self.out[key] = (ws, wt, Np, fused_bias)
+        self.n, self.rb, self.cb = len(rows), rb, cb
+        self.table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(device)
+
+    def valid(self, mode):
+        return self.mode == mode and all(W.data_ptr() == ptr for W, ptr in self.ptrs)
+
+    def refresh(self):
+        L.check(L.lib.ser_split_bf16_both_multi(self.table.data_ptr(), self.n, self.rb, self.cb, L.stream_ptr()), "ser_split_bf16_both_multi")
+        return self
+
+    def get(self, key):
+        return self.out.get(key)
+
+
+def weight_planes(model, entries_fn, rows):
+    """The encoder's WeightPlanes for this step - built once (persistent buffers, device descriptor table), refreshed by one launch -
+    or None when the layers are too small for the tile path (`_tile_ok`)."""
+    three_f = L.lib.ser_get_linear_forward_products() == 3
+    three_b = L.lib.ser_get_head_backward_products() == 3
+    wp = getattr(model, "_ft_weight_planes", None)
+    if wp is None or not wp.valid((three_f, three_b)):
+        entries = entries_fn()
+        if not entries or not all(_tile_ok(rows, sum(W.shape[0] for W, _ in mats), mats[0][0].shape[1]) for mats in entries.values()):
+            model._ft_weight_planes = None
+            return None
+        dev = next(iter(entries.values()))[0][0].device
+        wp = model._ft_weight_planes = WeightPlanes(entries, three_f, three_b, dev)
+    return wp.refresh()
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b on contiguous fp32 [M, K].
 
@@ -116,7 +186,8 @@ class _Linear(torch.autograd.Function):
     backward `ser_get_head_backward_products`.  Smaller layers keep the head's kernels."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, prepared=None):
+        """prepared: (ws, wt, Np, bias) of W from the step's WeightPlanes - the planes of W and W^T already exist."""
         ctx.save_for_backward(x, W)
         ctx.has_b = b is not None
         M, K = x.shape
@@ -126,11 +197,14 @@ class _Linear(torch.autograd.Function):
             return O.linear_fwd(x, W, b)
         three = L.lib.ser_get_linear_forward_products() == 3
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
-        if any(ctx.needs_input_grad):                             # (grad mode is off inside forward: this is the "will backward run" test)
+        if any(ctx.needs_input_grad[:3]):                         # (grad mode is off inside forward: this is the "will backward run" test)
             # one pass over x and one over W produce the forward operands AND the transposed ones of the backward products
             three_b = L.lib.ser_get_head_backward_products() == 3
             xs, xt, Mp = L.split_bf16_both(x, three, three_b)
-            ws, wt, Np = L.split_bf16_both(W, three, three_b)
+            if prepared is not None:
+                ws, wt, Np = prepared[:3]
+            else:
+                ws, wt, Np = L.split_bf16_both(W, three, three_b)
             ctx.planes_t = (xt, Mp, wt, Np, three_b)
             _nt(_ptrs(xs, three), K, _ptrs(ws, three), K, M, N, K, y, b)
             return y
@@ -150,7 +224,7 @@ class _Linear(torch.autograd.Function):
         if not ctx.tile:
             dx = O.linear_dgrad(dy, W) if ctx.needs_input_grad[0] else None
             _wgrad_now(dy, x, dW, db)
-            return dx, dW, db
+            return dx, dW, db, None
         three = L.lib.ser_get_head_backward_products() == 3
         saved = ctx.planes_t if (ctx.planes_t is not None and ctx.planes_t[4] == three) else None
         ctx.planes_t = None
@@ -169,12 +243,52 @@ class _Linear(torch.autograd.Function):
         _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)        # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
         if db is not None:                                       # second stage: the Mp / 32 block sums, in block order
             L.check(L.lib.ser_colsum(L.ptr(part), part.shape[0], N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
-        return dx, dW, db
+        return dx, dW, db, None
 
 
-def linear(x, W, b=None):
+class _LinearQKV(torch.autograd.Function):
+    """[q | k | v] = x [Wq; Wk; Wv]^T + [bq | bk | bv] as ONE product per direction on the fused operand planes of the step's
+    WeightPlanes (no concatenation of the weights): forward, dx = dy W, dW = dy^T x; the three weight / bias gradients are the row
+    blocks of one [3 H, K] / [3 H] result."""
+
+    @staticmethod
+    def forward(ctx, x, Wq, Wk, Wv, bq, bk, bv, prepared):
+        ws, wt, Np, bias = prepared
+        M, K = x.shape
+        N = ws.shape[0]
+        three = L.lib.ser_get_linear_forward_products() == 3
+        three_b = L.lib.ser_get_head_backward_products() == 3
+        xs, xt, Mp = L.split_bf16_both(x, three, three_b)
+        ctx.planes_t = (xt, Mp, wt, Np, three_b)
+        ctx.dims = (M, N, K, [int(Wq.shape[0]), int(Wk.shape[0]), int(Wv.shape[0])])
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        _nt(_ptrs(xs, three), K, _ptrs(ws, three), K, M, N, K, y, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xt, Mp, wt, Np, three = ctx.planes_t
+        ctx.planes_t = None
+        M, N, K, parts = ctx.dims
+        assert three == (L.lib.ser_get_head_backward_products() == 3), "the backward product count changed between forward and backward"
+        dy = dy.contiguous()
+        dys, dyt, Mp2, part = L.split_bf16_both(dy, three, three, colpart=True)
+        assert Mp2 == Mp
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+            _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
+        dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+        _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)
+        db = torch.empty(N, dtype=torch.float32, device=dy.device)
+        L.check(L.lib.ser_colsum(L.ptr(part), part.shape[0], N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
+        a, b_ = parts[0], parts[0] + parts[1]
+        return dx, dW[:a], dW[a:b_], dW[b_:], db[:a], db[a:b_], db[b_:], None
+
+
+def linear(x, W, b=None, prepared=None):
     shp = x.shape
-    y = _Linear.apply(x.reshape(-1, shp[-1]).contiguous(), W, b)
+    y = _Linear.apply(x.reshape(-1, shp[-1]).contiguous(), W, b, prepared)
     return y.reshape(*shp[:-1], W.shape[0])
 
 
@@ -656,23 +770,40 @@ def normalise_waves(wave):
     return out
 
 
-def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask, noise=None, layer=0):
+def _layer_entries(p, prefixes, names):
+    """WeightPlanes entries of transformer layers: q | k | v stacked into one operand, the other three Linears on their own."""
+    g = lambda pre, n: (p[pre + names[n] + ".weight"], p[pre + names[n] + ".bias"])
+    out = {}
+    for pre in prefixes:
+        out[pre + "qkv"] = [g(pre, "q"), g(pre, "k"), g(pre, "v")]
+        for n in ("o", "f1", "f2"):
+            out[pre + n] = [g(pre, n)]
+    return out
+
+
+def _transformer_layer(h, p, prefix, names, B, S, heads, eps, key_mask, noise=None, layer=0, wp=None):
     """Post-LN block (hf wav2vec2 :591-608 / xlm_roberta :421-463), h [B*S, H].  With `noise`: attention-probability,
-    hidden (after the attention output and after the FFN output) and activation dropout, as the HF modules place them."""
+    hidden (after the attention output and after the FFN output) and activation dropout, as the HF modules place them.
+    wp: the step's WeightPlanes (operand planes of every Linear weight of the encoder, refreshed by one launch)."""
     g = lambda n: p[prefix + n]
-    # q, k, v as ONE product over the concatenated weights (a copy of 3 H^2 values per layer and step; autograd slices the
-    # weight gradient back): one split of h, one launch, N = 3 H
+    pre = (lambda n: wp.get(prefix + n)) if wp is not None else (lambda n: None)
     Hd = h.shape[1]
-    qkv = linear(h, torch.cat([g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight")], dim=0),
-                 torch.cat([g(names["q"] + ".bias"), g(names["k"] + ".bias"), g(names["v"] + ".bias")], dim=0))
+    if wp is not None:
+        qkv = _LinearQKV.apply(h.contiguous(), g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight"),
+                               g(names["q"] + ".bias"), g(names["k"] + ".bias"), g(names["v"] + ".bias"), pre("qkv"))
+    else:
+        # q, k, v as ONE product over the concatenated weights (a copy of 3 H^2 values per layer and step; autograd slices the
+        # weight gradient back): one split of h, one launch, N = 3 H
+        qkv = linear(h, torch.cat([g(names["q"] + ".weight"), g(names["k"] + ".weight"), g(names["v"] + ".weight")], dim=0),
+                     torch.cat([g(names["q"] + ".bias"), g(names["k"] + ".bias"), g(names["v"] + ".bias")], dim=0))
     adrop = O.dropout_ctx(noise.p_attn) if noise is not None else None
     ctx = _AttentionQKV.apply(qkv, key_mask, B, S, heads, adrop, noise.site(layer, 0) if noise is not None else 0)
-    a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"))
+    a = linear(ctx, g(names["o"] + ".weight"), g(names["o"] + ".bias"), pre("o"))
     ph = noise.p_hidden if noise is not None else 0.0
     st = (lambda k: noise.site(layer, k)) if noise is not None else (lambda k: 0)
     h = layer_norm_drop(a, g(names["ln1"] + ".weight"), g(names["ln1"] + ".bias"), eps, h, noise, ph, st(1))
-    f = gelu_drop(linear(h, g(names["f1"] + ".weight"), g(names["f1"] + ".bias")), noise, noise.p_act if noise is not None else 0.0, st(2))
-    f = linear(f, g(names["f2"] + ".weight"), g(names["f2"] + ".bias"))
+    f = gelu_drop(linear(h, g(names["f1"] + ".weight"), g(names["f1"] + ".bias"), pre("f1")), noise, noise.p_act if noise is not None else 0.0, st(2))
+    f = linear(f, g(names["f2"] + ".weight"), g(names["f2"] + ".bias"), pre("f2"))
     return layer_norm_drop(f, g(names["ln2"] + ".weight"), g(names["ln2"] + ".bias"), eps, h, noise, ph, st(3))
 
 
@@ -704,7 +835,7 @@ def wav2vec2_forward(model, wave, noise=None):
     X0 = xp.as_strided((B * Lp[1], kpad), (s0, 1)).contiguous()
     w0 = p["feature_extractor.conv_layers.0.conv.weight"]                 # [C, 1, k]
     W0 = torch.nn.functional.pad(w0.reshape(w0.shape[0], k0), (0, kpad - k0))
-    h = _Linear.apply(X0, W0.contiguous(), None)
+    h = _Linear.apply(X0, W0.contiguous(), None, None)
     h = torch.cat([h, h.new_zeros(SLACK, h.shape[1])], dim=0)
     h = _ColNorm.apply(h, p["feature_extractor.conv_layers.0.layer_norm.weight"], p["feature_extractor.conv_layers.0.layer_norm.bias"],
                        1e-5, B, Lv[1], Lp[1])
@@ -741,16 +872,17 @@ def wav2vec2_forward(model, wave, noise=None):
     h = layer_norm(gelu(pc), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps, residual=z)   # LN(z + GELU(conv))
     if noise is not None:
         h = _drop(h, noise, noise.p_hidden, SITE0 + 401)
+    wp = weight_planes(model, lambda: _layer_entries(p, [f"encoder.layers.{i}." for i in range(c.num_hidden_layers)], W2V), B * S)
     for i in range(c.num_hidden_layers):
         if noise is not None and noise.static and noise.layerdrop > 0:
             # captured step: the layer always runs; a dropped layer's output is discarded by a select on a device word (its
             # backward then sees zeros, and the optimizer leaves its parameters untouched through the same word)
-            hn = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i)
+            hn = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i, wp)
             h = torch.where(noise.skip_dev[i] != 0, h, hn)
             continue
         if noise is not None and i in noise.skip:     # LayerDrop (hf :700-703)
             continue
-        h = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i)
+        h = _transformer_layer(h, p, f"encoder.layers.{i}.", W2V, B, S, c.num_attention_heads, eps, None, noise, i, wp)
     return h.reshape(B, S, H)
 
 
@@ -770,6 +902,7 @@ def xlmr_forward(model, ids, attn_mask, noise=None):
             noise.plan(c.num_hidden_layers, B, S)
         h = _drop(h, noise, noise.p_hidden, SITE0 + 500 + 402)
     mask = attn_mask.to(torch.float32).contiguous()
+    wp = weight_planes(model, lambda: _layer_entries(p, [f"encoder.layer.{i}." for i in range(c.num_hidden_layers)], XLMR), B * S)
     for i in range(c.num_hidden_layers):
-        h = _transformer_layer(h, p, f"encoder.layer.{i}.", XLMR, B, S, c.num_attention_heads, c.layer_norm_eps, mask, noise, i)
+        h = _transformer_layer(h, p, f"encoder.layer.{i}.", XLMR, B, S, c.num_attention_heads, c.layer_norm_eps, mask, noise, i, wp)
     return h.reshape(B, S, -1)
