@@ -76,13 +76,13 @@ int ser_split_bf16_both(const float* x, int R, int C, long long ldx, uint16_t* s
  * split anyway - in a fixed order, without another pass over x. */
 int ser_split_bf16_both_colsum(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
                                uint16_t* t_lo, int Rp, float* colpart, void* stream);
-/* ... for many matrices in one launch: `table` = nprob descriptors in device memory, 14 64-bit words each
- * {x, s_hi, s_lo, t_hi, t_lo, R, C, Rp, t_roff, ldx, cover, bias_src, bias_dst, bias_n}: a matrix may be a row block of a vertically
- * fused operand (q | k | v weights: straight planes from its own first row, transposed planes at row offset t_roff of the fused
- * operand's Rp-long rows); cover = rows walked (R, or a stand-alone matrix's padded Rp: zero-filled); optional bias copy.
- * rblocks / cblocks = largest cover / 32 and C / 32.  The fine-tuning encoders refresh every Linear weight's operand planes with
- * it once per step. */
-int ser_split_bf16_both_multi(const void* table, int nprob, int rblocks, int cblocks, void* stream);
+/* ... for many matrices in one launch: `table` = nprob descriptors in device memory, 16 64-bit words each
+ * {x, s_hi, s_lo, t_hi, t_lo, R, C, Rp, t_roff, ldx, cover, bias_src, bias_dst, bias_n, blk0, cblocks}: a matrix may be a row block of
+ * a vertically fused operand (q | k | v weights: straight planes from its own first row, transposed planes at row offset t_roff of
+ * the fused operand's Rp-long rows); cover = rows walked (R, or a stand-alone matrix's padded Rp: zero-filled); optional bias
+ * copy; blk0 = the matrix's first workgroup in the launch (ascending from 0), cblocks = C / 32; total_blocks = the sum of
+ * (cover / 32) x cblocks.  The fine-tuning encoders refresh every Linear weight's operand planes with it once per step. */
+int ser_split_bf16_both_multi(const void* table, int nprob, long long total_blocks, void* stream);
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual, split-bf16 operands, fp32 accumulate.
  * Replaces every torch.nn.Linear / Conv1d-as-GEMM inside the frozen encoders

@@ -163,7 +163,7 @@ def split_bf16_t(x, want_lo=True, pad=64, out=None):
 _sig("ser_split_bf16_both", i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp)
 
 
-_sig("ser_split_bf16_both_multi", i32, vp, i32, i32, i32, vp)
+_sig("ser_split_bf16_both_multi", i32, vp, i32, i64, vp)
 _sig("ser_split_bf16_both_colsum", i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp)
 
 

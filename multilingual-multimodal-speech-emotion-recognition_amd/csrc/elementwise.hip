@@ -166,15 +166,24 @@ struct SplitDesc {
   const float* x; bf16_t* s_hi; bf16_t* s_lo; bf16_t* t_hi; bf16_t* t_lo;
   long long R, C, Rp, t_roff, ldx, cover;
   const float* bias_src; float* bias_dst; long long bias_n;
+  long long blk0, cblocks;                             // first workgroup of this matrix in the launch, its 32-column blocks
 };
-__global__ __launch_bounds__(256) void split_both_multi_kernel(const SplitDesc* __restrict__ tab) {
-  const SplitDesc d = tab[blockIdx.z];
+__global__ __launch_bounds__(256) void split_both_multi_kernel(const SplitDesc* __restrict__ tab, int nprob) {
+  // the launch has exactly the workgroups the matrices need (sum of cover / 32 x C / 32): find this one's matrix by bisection
+  // over the descriptors' first-workgroup numbers
+  const long long bid = blockIdx.x;
+  int lo = 0, hi = nprob - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= bid) lo = mid; else hi = mid - 1;
+  }
+  const SplitDesc d = tab[lo];
+  const long long local = bid - d.blk0;
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && d.bias_src != nullptr)
+  const int r0 = (int)(local / d.cblocks) * 32, c0 = (int)(local % d.cblocks) * 32;
+  if (local == 0 && d.bias_src != nullptr)
     for (int i = threadIdx.x; i < d.bias_n; i += 256) d.bias_dst[i] = d.bias_src[i];
-  if (r0 >= d.cover || c0 >= d.C) return;              // workgroup-uniform
   const int R = (int)d.R, C = (int)d.C;
   const bool s_il = d.s_lo != nullptr, t_il = d.t_lo != nullptr;
 #pragma unroll
@@ -211,12 +220,12 @@ __global__ __launch_bounds__(256) void split_both_multi_kernel(const SplitDesc* 
     }
   }
 }
-// table: nprob descriptors of 14 64-bit words each in DEVICE memory (layout of SplitDesc); rblocks / cblocks: the largest
-// cover / 32 and C / 32 among them.  Every C and t_roff must be a multiple of 32, every Rp and cover a multiple of 32.
-extern "C" int ser_split_bf16_both_multi(const void* table, int nprob, int rblocks, int cblocks, void* stream) {
-  SER_REQUIRE(table && nprob > 0 && nprob <= 65535 && rblocks > 0 && cblocks > 0, "split_bf16_both_multi: bad arguments");
-  static_assert(sizeof(SplitDesc) == 14 * 8, "descriptor layout");
-  hipLaunchKernelGGL(split_both_multi_kernel, dim3(rblocks, cblocks, nprob), dim3(256), 0, (hipStream_t)stream, (const SplitDesc*)table);
+// table: nprob descriptors of 16 64-bit words each in DEVICE memory (layout of SplitDesc), blk0 ascending from 0; total_blocks =
+// sum over the matrices of (cover / 32) x (C / 32).  Every C and t_roff must be a multiple of 32, every Rp and cover a multiple of 32.
+extern "C" int ser_split_bf16_both_multi(const void* table, int nprob, long long total_blocks, void* stream) {
+  SER_REQUIRE(table && nprob > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "split_bf16_both_multi: bad arguments");
+  static_assert(sizeof(SplitDesc) == 16 * 8, "descriptor layout");
+  hipLaunchKernelGGL(split_both_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const SplitDesc*)table, nprob);
   SER_LAUNCH_CHECK();
   return SER_OK;
 }

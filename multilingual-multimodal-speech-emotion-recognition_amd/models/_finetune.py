@@ -119,7 +119,7 @@ class WeightPlanes:
         self.mode = (bool(three_f), bool(three_b))
         self.out, rows = {}, []
         self.ptrs = []
-        rb = cb = 1
+        blk = 0
         for key, mats in entries.items():
             K = mats[0][0].shape[1]
             N = sum(int(W.shape[0]) for W, _ in mats)
@@ -140,19 +140,19 @@ class WeightPlanes:
                 copy = len(mats) > 1 and b is not None and fused_bias is not None
                 rows.append([W.data_ptr(), s_hi, s_hi + 2 * L.IL_GROUP if three_f else 0, wt.data_ptr(),
                              wt.data_ptr() + 2 * L.IL_GROUP if three_b else 0, R, K, Np, r0, K, cover,
-                             b.data_ptr() if copy else 0, fused_bias.data_ptr() + 4 * r0 if copy else 0, R if copy else 0])
+                             b.data_ptr() if copy else 0, fused_bias.data_ptr() + 4 * r0 if copy else 0, R if copy else 0, blk, K // 32])
                 self.ptrs.append((W, W.data_ptr()))
-                rb, cb = max(rb, cover // 32), max(cb, K // 32)
+                blk += (cover // 32) * (K // 32)
                 r0 += R
             self.out[key] = (ws, wt, Np, fused_bias)
-        self.n, self.rb, self.cb = len(rows), rb, cb
+        self.n, self.blocks = len(rows), blk
         self.table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(device)
 
     def valid(self, mode):
         return self.mode == mode and all(W.data_ptr() == ptr for W, ptr in self.ptrs)
 
     def refresh(self):
-        L.check(L.lib.ser_split_bf16_both_multi(self.table.data_ptr(), self.n, self.rb, self.cb, L.stream_ptr()), "ser_split_bf16_both_multi")
+        L.check(L.lib.ser_split_bf16_both_multi(self.table.data_ptr(), self.n, self.blocks, L.stream_ptr()), "ser_split_bf16_both_multi")
         return self
 
     def get(self, key):
