@@ -412,6 +412,18 @@ int ser_colnorm_bwd(const float* dy, const float* x, const float* mean, const fl
                     int L, int Ls, int C, float* dx, float* dgamma, float* dbeta, int accumulate, void* workspace, void* stream);
 /* Adjoint of the positional conv's window view: dslab[r][c] = sum_j dwin[r - j][j * Cg + c] (hf :326-368). */
 int ser_toeplitz_add(const float* dwin, int rows_win, int K, int Cg, int rows_slab, float* dslab, void* stream);
+/* The positional conv of the fine-tuning path on the frozen encoders' resident-slab kernel (csrc/posconv.hip; K = 128 taps, 48 or 64
+ * channels per group, S <= 352 / 224 frames: ser_posconv_direct_supported).  ser_posconv_pack: Wp [H][Cg][K] fp32 (hf conv weight
+ * after weight-norm) -> the kernel's operand (H * K * 128 bf16: per row and tap the interleaved hi / lo planes of 64 zero-padded
+ * channels); flip = 1 packs the operand of the input-gradient correlation (rows = in channels, channels = out channels, taps
+ * reversed).  ser_posconv_fwd: out = GELU(conv(z) + bias) + z, raw (optional) = conv(z) + bias.  ser_posconv_dgrad:
+ * dz = conv^T(dpre) + add with the flip = 1 operand.  Three bf16 products per multiply (hf modeling_wav2vec2.py:326-368). */
+int ser_posconv_direct_supported(int S, int H, int G, int K);
+int ser_posconv_pack(const float* wp, int H, int G, int K, int flip, uint16_t* packed, void* stream);
+int ser_posconv_fwd(const float* z, const uint16_t* packed, const float* bias, int B, int S, int H, int G, int K, float* out, float* raw,
+                    void* stream);
+int ser_posconv_dgrad(const float* dpre, const uint16_t* packed_flip, const float* add, int B, int S, int H, int G, int K, float* dz,
+                      void* stream);
 /* Adjoint of a strided Conv1d's window view (the feature extractor's layers 1-6, hf :266-300, channels-last rows):
  * dx[r][c] = sum over taps j with r - j = s m, 0 <= m < M, of dwin[m][j * Cin + c]; every one of the rows_in rows is written. */
 int ser_conv_col2im(const float* dwin, int M, int k, int s, int Cin, long long rows_in, float* dx, void* stream);

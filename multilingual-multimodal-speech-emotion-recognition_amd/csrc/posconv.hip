@@ -30,10 +30,16 @@ constexpr int PC_WAVES = PC_THREADS / 64;
 SER_DEVFN int pc_off(int row, int chunk) { return row * PC_RB + ((chunk ^ ((row & 7) << 1)) << 4); }
 
 // MAXRB: 16-frame blocks a workgroup can hold (S <= 16 MAXRB); NCB: 16-channel blocks of the group (C_g = 16 NCB)
-template <int MAXRB, int NCB>
+// EPI 0 (forward): v = acc + bias; out = GELU(v) + z; `raw` (optional) keeps v for backward.
+// EPI 1 (a correlation with prepared weights, no activation): out = acc + add - the input gradient of the same conv is this kernel
+// over the pre-activation gradient with the taps reversed and the channel roles swapped (ser_posconv_pack, flip) and the window
+// moved by one frame (shift = 1: the even kernel's padding is K/2 in front and K/2 - 1 behind), `add` = the residual branch's
+// gradient.
+template <int MAXRB, int NCB, int EPI>
 __global__ __launch_bounds__(PC_THREADS) void posconv_direct_kernel(const float* __restrict__ z, const bf16_t* __restrict__ w,
                                                                      const float* __restrict__ bias, float* __restrict__ out,
-                                                                     int S, int H, int G) {
+                                                                     int S, int H, int G, float* __restrict__ raw,
+                                                                     const float* __restrict__ add, int shift) {
   constexpr int RBW = (MAXRB + PC_WAVES - 1) / PC_WAVES;     // row blocks per wave
   constexpr int SLAB_ROWS = MAXRB * 16 + PC_K - 1;
   constexpr int WROWS = NCB * 16;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(PC_THREADS) void posconv_direct_kernel(const float*
 
   // ---- the group's input, split into planes: slab row r = frame r - K/2, zero outside [0, S) and beyond C_g
   for (int item = tid; item < rows * 8; item += PC_THREADS) {
-    const int r = item >> 3, h = (item >> 2) & 1, q = item & 3, t = r - PC_K / 2, c0 = h * 32 + q * 8;
+    const int r = item >> 3, h = (item >> 2) & 1, q = item & 3, t = r - PC_K / 2 + shift, c0 = h * 32 + q * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (t >= 0 && t < S && c0 < Cg) {
       const float4 a = *(const float4*)(zb + (long long)t * H + c0), c = *(const float4*)(zb + (long long)t * H + c0 + 4);
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(PC_THREADS) void posconv_direct_kernel(const float*
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = cb * 16 + fr;
     if (n >= Cg) continue;
-    const float bv = bias[g * Cg + n];
+    const float bv = EPI == 0 ? bias[g * Cg + n] : 0.f;
 #pragma unroll
     for (int i = 0; i < RBW; ++i) {
       const int rb = wave + PC_WAVES * i;
@@ -146,7 +152,15 @@ __global__ __launch_bounds__(PC_THREADS) void posconv_direct_kernel(const float*
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = rb * 16 + fq * 4 + r;
-        if (t < S) ob[(long long)t * H + n] = __fadd_rn(gelu_erf(__fadd_rn(acc[i][cb][r], bv)), zb[(long long)t * H + n]);
+        if (t >= S) continue;
+        const long long o = (long long)t * H + n;
+        if (EPI == 0) {
+          const float v = __fadd_rn(acc[i][cb][r], bv);
+          if (raw) raw[(long long)b * S * H + g * Cg + o] = v;
+          ob[o] = __fadd_rn(gelu_erf(v), zb[o]);
+        } else {
+          ob[o] = __fadd_rn(acc[i][cb][r], add[(long long)b * S * H + g * Cg + o]);
+        }
       }
     }
   }
@@ -160,17 +174,73 @@ int ser_posconv_direct_ok(int S, int H, int G, int K) {
   return K == PC_K && G > 0 && H % G == 0 && (Cg == 48 || Cg == 64) && S >= 1 && S <= 22 * 16 && (Cg == 48 || S <= 14 * 16);
 }
 
-int ser_launch_posconv_direct(const float* z, const bf16_t* w_il, const float* bias, float* out, int B, int S, int H, int G, int K,
-                              hipStream_t st) {
-  SER_REQUIRE(ser_posconv_direct_ok(S, H, G, K), "posconv (resident slab): unsupported geometry S=%d H=%d G=%d K=%d", S, H, G, K);
+template <int EPI>
+static int launch_direct(const float* z, const bf16_t* w_il, const float* bias, float* out, int B, int S, int H, int G, float* raw,
+                         const float* add, int shift, hipStream_t st) {
   const int Cg = H / G;
   const dim3 grid(B * G), block(PC_THREADS);
   if (Cg == 48) {
-    if (S <= 14 * 16) hipLaunchKernelGGL((posconv_direct_kernel<14, 3>), grid, block, 0, st, z, w_il, bias, out, S, H, G);
-    else hipLaunchKernelGGL((posconv_direct_kernel<22, 3>), grid, block, 0, st, z, w_il, bias, out, S, H, G);
+    if (S <= 14 * 16) hipLaunchKernelGGL((posconv_direct_kernel<14, 3, EPI>), grid, block, 0, st, z, w_il, bias, out, S, H, G, raw, add, shift);
+    else hipLaunchKernelGGL((posconv_direct_kernel<22, 3, EPI>), grid, block, 0, st, z, w_il, bias, out, S, H, G, raw, add, shift);
   } else {
-    hipLaunchKernelGGL((posconv_direct_kernel<14, 4>), grid, block, 0, st, z, w_il, bias, out, S, H, G);
+    hipLaunchKernelGGL((posconv_direct_kernel<14, 4, EPI>), grid, block, 0, st, z, w_il, bias, out, S, H, G, raw, add, shift);
   }
   SER_LAUNCH_CHECK();
   return SER_OK;
+}
+
+int ser_launch_posconv_direct(const float* z, const bf16_t* w_il, const float* bias, float* out, int B, int S, int H, int G, int K,
+                              hipStream_t st) {
+  SER_REQUIRE(ser_posconv_direct_ok(S, H, G, K), "posconv (resident slab): unsupported geometry S=%d H=%d G=%d K=%d", S, H, G, K);
+  return launch_direct<0>(z, w_il, bias, out, B, S, H, G, nullptr, nullptr, 0, st);
+}
+
+namespace {
+// Wp [H][Cg][K] fp32 (hf layout of the weight-normed conv weight: out channel, in channel of the group, tap) -> the kernel's
+// operand [G][Cg rows][K taps][128]: per (row, tap) the interleaved planes of 64 (zero-padded) channels
+// [hi 0..31 | lo 0..31 | hi 32..63 | lo 32..63].  flip = 0: row = out channel, channel = in channel, tap as is (forward);
+// flip = 1: row = IN channel, channel = OUT channel, taps reversed (the input-gradient correlation).
+__global__ void posconv_pack_kernel(const float* __restrict__ wp, int H, int Cg, int flip, bf16_t* __restrict__ out) {
+  const long long n_items = (long long)H * PC_K * PC_CP;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (long long)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % PC_CP);
+    const int j = (int)((i / PC_CP) % PC_K);
+    const int rowg = (int)(i / ((long long)PC_CP * PC_K));      // g * Cg + row
+    const int g = rowg / Cg, row = rowg % Cg;
+    float v = 0.f;
+    if (ch < Cg) v = flip ? wp[((long long)(g * Cg + ch) * Cg + row) * PC_K + (PC_K - 1 - j)] : wp[((long long)rowg * Cg + ch) * PC_K + j];
+    bf16_t h, l;
+    split_bf16(v, h, l);
+    bf16_t* o = out + ((long long)rowg * PC_K + j) * (2 * PC_CP) + (ch >> 5) * 64 + (ch & 31);
+    o[0] = h;
+    o[32] = l;
+  }
+}
+}  // namespace
+
+extern "C" int ser_posconv_direct_supported(int S, int H, int G, int K) { return ser_posconv_direct_ok(S, H, G, K); }
+
+/* packed: H * K * 128 bf16 values */
+extern "C" int ser_posconv_pack(const float* wp, int H, int G, int K, int flip, uint16_t* packed, void* stream) {
+  SER_REQUIRE(wp && packed && K == PC_K && G > 0 && H % G == 0 && H / G <= PC_CP, "posconv_pack: unsupported geometry H=%d G=%d K=%d", H, G, K);
+  const long long n = (long long)H * PC_K * PC_CP;
+  hipLaunchKernelGGL(posconv_pack_kernel, dim3((unsigned)((n + 255) / 256 > 65535 * 8 ? 65535 * 8 : (n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, wp, H, H / G, flip, (bf16_t*)packed);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
+/* out = GELU(conv(z) + bias) + z on [B, S, H] with the packed weights (flip = 0); raw (optional) = conv(z) + bias */
+extern "C" int ser_posconv_fwd(const float* z, const uint16_t* packed, const float* bias, int B, int S, int H, int G, int K, float* out,
+                               float* raw, void* stream) {
+  SER_REQUIRE(z && packed && bias && out && ser_posconv_direct_ok(S, H, G, K), "posconv_fwd: unsupported geometry S=%d H=%d G=%d K=%d", S, H, G, K);
+  return launch_direct<0>(z, (const bf16_t*)packed, bias, out, B, S, H, G, raw, nullptr, 0, (hipStream_t)stream);
+}
+
+/* dz = conv^T(dpre) + add on [B, S, H] with the packed weights of flip = 1 (the input gradient of the conv itself, plus the
+ * gradient `add` of whatever else consumed z) */
+extern "C" int ser_posconv_dgrad(const float* dpre, const uint16_t* packed_flip, const float* add, int B, int S, int H, int G, int K,
+                                 float* dz, void* stream) {
+  SER_REQUIRE(dpre && packed_flip && add && dz && ser_posconv_direct_ok(S, H, G, K), "posconv_dgrad: unsupported geometry S=%d H=%d G=%d K=%d", S, H, G, K);
+  return launch_direct<1>(dpre, (const bf16_t*)packed_flip, nullptr, dz, B, S, H, G, nullptr, add, 1, (hipStream_t)stream);
 }

@@ -39,6 +39,10 @@ _sig("ser_colnorm_fwd", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.f
 _sig("ser_colnorm_bwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.i32, L.vp, L.vp)
 _sig("ser_toeplitz_add", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 _sig("ser_conv_col2im", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.i64, L.vp, L.vp)
+_sig("ser_posconv_direct_supported", L.i32, L.i32, L.i32, L.i32, L.i32)
+_sig("ser_posconv_pack", L.i32, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
+_sig("ser_posconv_fwd", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp)
+_sig("ser_posconv_dgrad", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 _sig("ser_embed_fwd", L.i32, L.vp, L.vp, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 _sig("ser_embed_bwd", L.i32, L.vp, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp, L.vp, L.vp)
 _sig("ser_wave_normalize", L.i32, L.vp, L.i32, L.i32, L.vp, L.vp, L.vp)
@@ -621,6 +625,58 @@ class _PosConv(torch.autograd.Function):
         return dz, dW2.view(H, K, Cg).permute(0, 2, 1), db, None, None, None, None
 
 
+class _PosConvDirect(torch.autograd.Function):
+    """GELU(posconv(z) + bias) + z - the positional conv, its activation and the residual add (hf :326-368, :706-708) - on the frozen
+    encoders' resident-slab kernel at the Base geometry (K = 128, 16 groups of 48; `ser_posconv_direct_supported`): the S + 127
+    rows of a (clip, group) live in LDS as split planes, only the weights stream.  Forward keeps the pre-activation; backward is
+    dpre = dout . GELU'(pre), then the SAME kernel as a correlation over dpre with the taps reversed and the channel roles swapped
+    (+ dout for the residual branch) for dz, and the window-view products of `_PosConv` for the weight gradient.  Three products per
+    multiply in both precision modes."""
+
+    @staticmethod
+    def forward(ctx, z, Wp, bias, B, S, K, G):
+        z, Wp, bias = z.contiguous(), Wp.contiguous(), bias.contiguous()
+        H = z.shape[1]
+        packed = torch.empty(H * K * 128, dtype=torch.bfloat16, device=z.device)
+        L.check(L.lib.ser_posconv_pack(L.ptr(Wp), H, G, K, 0, packed.data_ptr(), L.stream_ptr()), "ser_posconv_pack")
+        out, pre = torch.empty_like(z), torch.empty_like(z)
+        L.check(L.lib.ser_posconv_fwd(L.ptr(z), packed.data_ptr(), L.ptr(bias), B, S, H, G, K, L.ptr(out), L.ptr(pre), L.stream_ptr()),
+                "ser_posconv_fwd")
+        ctx.save_for_backward(z, Wp, pre)
+        ctx.dims = (B, S, K, G)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, Wp, pre = ctx.saved_tensors
+        B, S, K, G = ctx.dims
+        H = z.shape[1]
+        Cg, R = H // G, S + K - 1
+        rows = B * R
+        dout = dout.contiguous()
+        dpre = torch.empty_like(dout)
+        L.check(L.lib.ser_gelu_bwd(L.ptr(dout), L.ptr(pre), dout.numel(), L.ptr(dpre), L.stream_ptr()), "ser_gelu_bwd")
+        dz = None
+        if ctx.needs_input_grad[0]:
+            packed = torch.empty(H * K * 128, dtype=torch.bfloat16, device=z.device)
+            L.check(L.lib.ser_posconv_pack(L.ptr(Wp), H, G, K, 1, packed.data_ptr(), L.stream_ptr()), "ser_posconv_pack")
+            dz = torch.empty_like(dout)
+            L.check(L.lib.ser_posconv_dgrad(L.ptr(dpre), packed.data_ptr(), L.ptr(dout), B, S, H, G, K, L.ptr(dz), L.stream_ptr()), "ser_posconv_dgrad")
+        # weight / bias gradients: per group dW2_g = dy_g^T . windows(slab_g) over the zero-padded slabs (see _PosConv)
+        slabs = torch.zeros(G, rows + K, Cg, dtype=torch.float32, device=z.device)
+        slabs[:, :rows].view(G, B, R, Cg)[:, :, K // 2:K // 2 + S] = z.view(B, S, G, Cg).permute(2, 0, 1, 3)
+        dy = torch.zeros(G, rows, Cg, dtype=torch.float32, device=z.device)
+        dy.view(G, B, R, Cg)[:, :, :S] = dpre.view(B, S, G, Cg).permute(2, 0, 1, 3)
+        dW2 = torch.empty(H, K * Cg, dtype=torch.float32, device=z.device)
+        db = torch.empty(H, dtype=torch.float32, device=z.device)
+        ws = torch.empty(int(L.lib.ser_colsum_tall_workspace_bytes(H)), dtype=torch.uint8, device=z.device)
+        L.check(L.lib.ser_colsum_tall(L.ptr(dpre), B * S, H, H, L.ptr(db), L.ptr(ws), L.stream_ptr()), "ser_colsum_tall")
+        np_ = L.lib.ser_get_head_backward_products()
+        for g in range(G):
+            _gemm(dy[g].data_ptr(), 1, Cg, slabs[g].data_ptr(), Cg, 1, Cg, K * Cg, rows, dW2[g * Cg:].data_ptr(), K * Cg, products=np_)
+        return dz, dW2.view(H, K, Cg).permute(0, 2, 1), db, None, None, None, None
+
+
 class _Embed(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ids, pos, wemb, pemb, temb, pad_id):
@@ -868,8 +924,13 @@ def wav2vec2_forward(model, wave, noise=None):
     Wp = g0 * v0 / torch.sqrt((v0 * v0).sum(dim=(0, 1), keepdim=True))                                      # [H, Cg, K]
     K, G = c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups
     Cg, R = H // G, S + K - 1
-    pc = _PosConv.apply(z.contiguous(), Wp, p["encoder.pos_conv_embed.conv.bias"], B, S, K, G)
-    h = layer_norm(gelu(pc), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps, residual=z)   # LN(z + GELU(conv))
+    if L.lib.ser_posconv_direct_supported(S, H, G, K) and z.is_cuda:
+        # GELU(conv) + z from the resident-slab kernel, then the LayerNorm alone
+        h = layer_norm(_PosConvDirect.apply(z.contiguous(), Wp, p["encoder.pos_conv_embed.conv.bias"], B, S, K, G),
+                       p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps)
+    else:
+        pc = _PosConv.apply(z.contiguous(), Wp, p["encoder.pos_conv_embed.conv.bias"], B, S, K, G)
+        h = layer_norm(gelu(pc), p["encoder.layer_norm.weight"], p["encoder.layer_norm.bias"], eps, residual=z)   # LN(z + GELU(conv))
     if noise is not None:
         h = _drop(h, noise, noise.p_hidden, SITE0 + 401)
     wp = weight_planes(model, lambda: _layer_entries(p, [f"encoder.layers.{i}." for i in range(c.num_hidden_layers)], W2V), B * S)

@@ -346,3 +346,30 @@ def test_captured_fine_tune_steps_equal_eager_steps_with_the_same_draws():
     # and the optimizer's moments of such a parameter stay untouched too
     oe, og = runs["eager"][3], runs["graph"][3]
     assert oe.t == og.t == len(batches)
+
+
+@pytest.mark.parametrize("S", [12, 199, 230])
+def test_positional_conv_node_on_the_resident_slab_kernel(S):
+    """`_PosConvDirect` (Base geometry: 128 taps, 16 groups of 48): GELU(conv(z) + b) + z and all three gradients against float64
+    autograd of torch's grouped conv1d with padding 64 and the last frame dropped (hf modeling_wav2vec2.py:326-368)."""
+    import ser_amd  # noqa: F401
+    from ser_amd.models._finetune import _PosConvDirect
+    dev = torch.device("cuda:0")
+    B, H, G, K = 2, 768, 16, 128
+    g = torch.Generator().manual_seed(S)
+    z = torch.randn(B * S, H, generator=g)
+    Wp = torch.randn(H, H // G, K, generator=g) / (K * H // G) ** 0.5          # pre-activations of unit scale
+    bias = 0.1 * torch.randn(H, generator=g)
+    dout = torch.randn(B * S, H, generator=g)
+    zd, wd, bd = (t_.double().requires_grad_() for t_ in (z, Wp, bias))
+    pre = torch.nn.functional.conv1d(zd.view(B, S, H).transpose(1, 2), wd, bd, padding=K // 2, groups=G)[:, :, :S].transpose(1, 2)
+    ref = (torch.nn.functional.gelu(pre) + zd.view(B, S, H)).reshape(B * S, H)
+    ref.backward(dout.double())
+    zg, wg, bg = (t_.to(dev).requires_grad_() for t_ in (z, Wp, bias))
+    out = _PosConvDirect.apply(zg, wg, bg, B, S, K, G)
+    out.backward(dout.to(dev))
+    torch.cuda.synchronize()
+    assert (out.detach().cpu() - ref.detach().float()).abs().max().item() < 5e-5       # three bf16 products per multiply, K Cg = 6144 terms
+    for got, want, name in ((zg.grad, zd.grad, "dz"), (wg.grad, wd.grad, "dW"), (bg.grad, bd.grad, "db")):
+        err = (got.cpu() - want.float()).abs().max().item()
+        assert err < 2e-4 * max(1.0, want.abs().max().item()), f"{name}: {err:.3e} (max {want.abs().max().item():.3e})"
