@@ -93,6 +93,11 @@ int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const 
                      const uint16_t* w_lo, int ldw, int M, int N, int K, const float* bias, int act,
                      const float* residual, int ldr, float* c_f32, uint16_t* c_hi, uint16_t* c_lo,
                      int ldc, void* stream);
+/* ... with the K range cut into ksplit (<= 8, <= K / 32) slices, interleaved three-product operands only: slabs = [ksplit][M][N]
+ * raw partial sums (no bias / activation / residual), added by the caller in slice order (ser_colsum over [ksplit, M * N]).  Used
+ * for the fine-tuning encoders' weight gradients: long K (tokens, conv frames), small output. */
+int ser_gemm_bf16_nt_splitk(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw,
+                            int M, int N, int K, int ksplit, float* slabs, void* stream);
 
 /* y = LayerNorm(x (+ x2)) * gamma + beta over the last dim D; fp32 in; fp32 and/or split out.
  * Replaces nn.LayerNorm in hf wav2vec2 :429,:601,:606 and xlm_roberta :336-340,:394-398. */

@@ -866,6 +866,22 @@ extern "C" int ser_debug_gemm_batched(const uint16_t* a, const uint16_t* w, int 
   return ser_launch_gemm_bf16(g, (hipStream_t)stream);
 }
 
+// NT product in the interleaved three-product mode with the K range cut into `ksplit` slices (<= 8): slabs = [ksplit][M][N] raw
+// partial sums, to be added by the caller in slice order (ser_colsum over [ksplit, M * N]).  For products whose K is long and whose
+// output is small - the weight gradients of the fine-tuning encoders (K = tokens of the batch, or conv frames): a handful of output
+// tiles would otherwise walk the whole K range on a handful of CUs.
+extern "C" int ser_gemm_bf16_nt_splitk(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo,
+                                       int ldw, int M, int N, int K, int ksplit, float* slabs, void* stream) {
+  SerGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a_hi = a_hi; g.a_lo = a_lo; g.w_hi = w_hi; g.w_lo = w_lo;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw;
+  g.nb1 = 1; g.nb2 = 1;
+  g.c_f32 = slabs; g.ldc = N;
+  g.ksplit = ksplit; g.slab_stride = (long long)M * N;
+  return ser_launch_gemm_bf16(g, (hipStream_t)stream);
+}
+
 // debug / probe entry: interleaved three-product GEMM with an explicit tile configuration and split-K factor;
 // c_f32 = [ksplit][M][N] slabs of raw partial sums when ksplit > 1, else the [M][N] result
 extern "C" int ser_debug_gemm_il_cfg(const uint16_t* a, const uint16_t* w, int M, int N, int K, int cfg, int ksplit, float* c_f32,

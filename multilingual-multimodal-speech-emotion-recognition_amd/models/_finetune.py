@@ -105,6 +105,24 @@ def _nt(a, lda, w, ldw, M, N, K, out, bias=None):
                                    out.data_ptr(), None, None, int(N), L.stream_ptr()), "ser_gemm_bf16_nt")
 
 
+L._sig("ser_gemm_bf16_nt_splitk", L.i32, L.vp, L.vp, L.i32, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
+
+
+def _nt_wgrad(a, lda, w, ldw, M, N, K, out, three):
+    """out[M,N] = A[M,K] . W[N,K]^T for a weight gradient: K = tokens of the batch (or conv frames) is long, the output small.  In
+    the three-product mode the K range is cut into slices on different workgroups (`ser_gemm_bf16_nt_splitk`) and the partial sums
+    are added in slice order by one column-sum launch; a few dozen output tiles would otherwise walk the whole range alone."""
+    ks = 1
+    if three and K >= 1024:
+        ks = 8 if K >= 3200 else 4
+    if ks == 1:
+        return _nt(a, lda, w, ldw, M, N, K, out)
+    slabs = torch.empty(ks, M * N, dtype=torch.float32, device=out.device)
+    L.check(L.lib.ser_gemm_bf16_nt_splitk(a[0], a[1], int(lda), w[0], w[1], int(ldw), int(M), int(N), int(K), ks, slabs.data_ptr(),
+                                          L.stream_ptr()), "ser_gemm_bf16_nt_splitk")
+    L.check(L.lib.ser_colsum(slabs.data_ptr(), ks, M * N, M * N, out.data_ptr(), 0, L.stream_ptr()), "ser_colsum")
+
+
 def _tile_ok(M, N, K):
     return M >= 64 and N % 64 == 0 and K % 64 == 0
 
@@ -244,7 +262,7 @@ class _Linear(torch.autograd.Function):
         dx = torch.empty(M, K, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
         if dx is not None:                                       # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
             _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
-        _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)        # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
+        _nt_wgrad(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW, three)   # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
         if db is not None:                                       # second stage: the Mp / 32 block sums, in block order
             L.check(L.lib.ser_colsum(L.ptr(part), part.shape[0], N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
         return dx, dW, db, None
@@ -283,7 +301,7 @@ class _LinearQKV(torch.autograd.Function):
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
             _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
         dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-        _nt(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW)
+        _nt_wgrad(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW, three)
         db = torch.empty(N, dtype=torch.float32, device=dy.device)
         L.check(L.lib.ser_colsum(L.ptr(part), part.shape[0], N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
         a, b_ = parts[0], parts[0] + parts[1]
@@ -367,7 +385,7 @@ class _ConvPad(torch.autograd.Function):
             assert Mp2 == Mp
             for j in range(k):                                                       # rows j*Cin.. of windows^T = (x[j::s])^T
                 L.split_bf16_t(x[j::s][:rows_out], three, out=winT[j * Cin:(j + 1) * Cin])
-            _nt(_ptrs(dyt, three), Mp, _ptrs(winT, three), Mp, Cout, k * Cin, Mp, dW2)
+            _nt_wgrad(_ptrs(dyt, three), Mp, _ptrs(winT, three), Mp, Cout, k * Cin, Mp, dW2, three)
             if dx is not None:
                 w2t = _planes_t(W2.contiguous(), three)                              # dwin[M, k Cin] = dy . W2
                 _nt(_ptrs(dys, three), Cout, w2t[1:3], w2t[3], rows_out, k * Cin, Cout, dwin)

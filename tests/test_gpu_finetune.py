@@ -373,3 +373,40 @@ def test_positional_conv_node_on_the_resident_slab_kernel(S):
     for got, want, name in ((zg.grad, zd.grad, "dz"), (wg.grad, wd.grad, "dW"), (bg.grad, bd.grad, "db")):
         err = (got.cpu() - want.float()).abs().max().item()
         assert err < 2e-4 * max(1.0, want.abs().max().item()), f"{name}: {err:.3e} (max {want.abs().max().item():.3e})"
+
+
+@pytest.mark.parametrize("M", [1592, 3300])
+def test_tile_path_linear_and_conv_gradients_with_split_k(M):
+    """`_Linear` and `_ConvPad` on the MFMA tile kernel at row counts where the weight gradient's K range (the rows) is cut into
+    4 / 8 slices (`ser_gemm_bf16_nt_splitk` + slice-order sum): outputs and all gradients against float64."""
+    import ser_amd  # noqa: F401
+    from ser_amd.models._finetune import SLACK, _ConvPad, _Linear
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(M)
+    K, N = 256, 192
+    x, W, b, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    xg, Wg, bg = (t_.to(dev).requires_grad_() for t_ in (x, W, b))
+    y = _Linear.apply(xg, Wg, bg, None)
+    y.backward(dy.to(dev))
+    xd, Wd, bd = (t_.double().requires_grad_() for t_ in (x, W, b))
+    (xd @ Wd.t() + bd).backward(dy.double())
+    assert (y.detach().cpu() - (x.double() @ W.double().t() + b.double()).float()).abs().max().item() < 5e-5      # three bf16 products per multiply
+    for got, want, name in ((xg.grad, xd.grad, "dx"), (Wg.grad, Wd.grad, "dW"), (bg.grad, bd.grad, "db")):
+        assert (got.cpu() - want.float()).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), name
+    # conv: C_in = C_out = 64, kernel 3, stride 2 on one padded buffer
+    Cin, Cout, k, s_ = 64, 64, 3, 2
+    rows_out = M
+    xin = torch.randn(s_ * rows_out + SLACK, Cin, generator=g)
+    W2 = torch.randn(Cout, k * Cin, generator=g) / (k * Cin) ** 0.5
+    dyc = torch.randn(rows_out + SLACK, Cout, generator=g)
+    dyc[rows_out:] = 0
+    xg2, Wg2 = xin.to(dev).requires_grad_(), W2.to(dev).requires_grad_()
+    yc = _ConvPad.apply(xg2, Wg2, k, s_, rows_out)
+    yc.backward(dyc.to(dev))
+    xd2, Wd2 = xin.double().requires_grad_(), W2.double().requires_grad_()
+    win = torch.stack([xd2[s_ * m:s_ * m + k].reshape(-1) for m in range(rows_out)])          # [rows_out, k Cin]
+    ref = win @ Wd2.t()
+    ref.backward(dyc[:rows_out].double())
+    assert (yc[:rows_out].detach().cpu() - ref.detach().float()).abs().max().item() < 5e-5
+    assert (Wg2.grad.cpu() - Wd2.grad.float()).abs().max().item() < 1e-4 * max(1.0, Wd2.grad.abs().max().item())
+    assert (xg2.grad.cpu() - xd2.grad.float()).abs().max().item() < 1e-4
