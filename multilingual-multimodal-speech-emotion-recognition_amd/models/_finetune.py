@@ -800,8 +800,13 @@ class Noise:
         n_layers, B, S = self._shape
         if self.skip_dev is None or self.skip_dev.numel() != n_layers or self.skip_dev.device != torch.device(device):
             self.skip_dev = torch.zeros(n_layers, dtype=torch.int32, device=device)
-        if self.spec_dev is None or self.spec_dev.numel() != B * S or self.spec_dev.device != torch.device(device):
-            self.spec_dev = torch.zeros(B * S, dtype=torch.bool, device=device)
+        # one persistent buffer per batch shape: a captured graph keeps reading the buffer it was captured with, so a shape's
+        # buffer must never be replaced (steps of several shapes alternate)
+        bufs = self.__dict__.setdefault("_spec_devs", {})
+        key = (B * S, str(torch.device(device)))
+        if key not in bufs:
+            bufs[key] = torch.zeros(B * S, dtype=torch.bool, device=device)
+        self.spec_dev = bufs[key]
         sk = np.zeros(n_layers, dtype=np.int32)
         sk[list(self.skip)] = 1
         self.skip_dev.copy_(torch.from_numpy(sk), non_blocking=False)

@@ -191,11 +191,11 @@ class SERSystem(nn.Module):
     def _ones_mask(self, seq):
         """[B, S] of ones (HF returns no attention mask for wav2vec2-base: ref audio_encoder.py:162-163), cached per shape so a
         step does not launch a fill kernel for it."""
-        key = (seq.shape[0], seq.shape[1], seq.device)
-        m = getattr(self, "_mask_cache", None)
-        if m is None or m[0] != key:
-            self._mask_cache = m = (key, torch.ones(seq.shape[0], seq.shape[1], dtype=torch.float32, device=seq.device))
-        return m[1]
+        key = (seq.shape[0], seq.shape[1], str(seq.device))
+        cache = self.__dict__.setdefault("_mask_cache", {})
+        if key not in cache:          # one tensor per shape, kept: a captured graph of another shape still reads its own
+            cache[key] = torch.ones(seq.shape[0], seq.shape[1], dtype=torch.float32, device=seq.device)
+        return cache[key]
 
     def _adapters(self, a_enc, t_enc):
         """Both residual adapters (independent): the text one on the side stream, or - GROUPED_HEAD - one grouped launch per level."""
