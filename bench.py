@@ -501,11 +501,13 @@ def main():
                                       "Large-sized (1024-d, 24-layer) Wav2Vec2 + XLM-R" if args.stress else "Wav2Vec2-Base + XLM-R-Base",
                                       "trained too (full fine-tune, 397 M parameters)" if args.unfreeze else "frozen"),
                        "global_batch": world * args.batch,
-                       "precision": (("fp32 tensors, every product = 3 bf16 MFMA products on operands split hi+lo on the fly, fp32 accumulate"
+                       "precision": (("fp32 tensors, every product = 3 bf16 MFMA products per multiply on operands split into bf16 hi+lo planes (encoder "
+                                      "Linear / conv layers: MFMA tile kernel; attention: fp32 matrix pipe), fp32 accumulate"
                                       if args.precision == "bf16x3" else
-                                      "AMP line (the reference's --use_amp, bf16 autocast): fp32 tensors, operands rounded to bf16 on the fly, 1 bf16 MFMA "
-                                      "product per multiply in the encoders' Linear layers and in every backward product, fp32 accumulate; head "
-                                      "forward stays 3 products; no 1e-3 parity claim")
+                                      "AMP line (the reference's --use_amp, bf16 autocast): fp32 tensors, operands rounded to bf16, 1 bf16 MFMA "
+                                      "product per multiply in the encoders' Linear and conv layers and in every backward product, fp32 accumulate; the "
+                                      "positional conv (resident-slab kernel), attention (fp32 matrix pipe) and the head's forward keep full-precision "
+                                      "products; no 1e-3 parity claim")
                                      if args.unfreeze else
                                      "bf16x3: operands split into bf16 hi+lo planes, 3 bf16 MFMA products per multiply, fp32 accumulate"
                                      if args.precision == "bf16x3" else "bf16: 1 bf16 MFMA product per multiply, fp32 accumulate (fast mode, no 1e-3 parity claim)"),
