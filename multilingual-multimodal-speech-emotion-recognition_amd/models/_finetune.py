@@ -108,12 +108,13 @@ def _nt(a, lda, w, ldw, M, N, K, out, bias=None):
 L._sig("ser_gemm_bf16_nt_splitk", L.i32, L.vp, L.vp, L.i32, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
 
 
-def _nt_wgrad(a, lda, w, ldw, M, N, K, out, three):
-    """out[M,N] = A[M,K] . W[N,K]^T for a weight gradient: K = tokens of the batch (or conv frames) is long, the output small.  In
-    the three-product mode the K range is cut into slices on different workgroups (`ser_gemm_bf16_nt_splitk`) and the partial sums
-    are added in slice order by one column-sum launch; a few dozen output tiles would otherwise walk the whole range alone."""
+def _nt_wgrad(a, lda, w, ldw, M, N, K, out, three, kmin=1024):
+    """out[M,N] = A[M,K] . W[N,K]^T for a product whose K is long and whose output is small - a weight gradient (K = tokens of the
+    batch, or conv frames), or the input gradient of a wide layer (K = 2 304 / 3 072 output features, kmin = 2048).  In the
+    three-product mode the K range is cut into slices on different workgroups (`ser_gemm_bf16_nt_splitk`) and the partial sums are
+    added in slice order by one column-sum launch; a hundred-odd output tiles would otherwise walk the whole range alone."""
     ks = 1
-    if three and K >= 1024:
+    if three and K >= kmin:
         ks = 8 if K >= 3200 else 4
     if ks == 1:
         return _nt(a, lda, w, ldw, M, N, K, out)
@@ -261,7 +262,7 @@ class _Linear(torch.autograd.Function):
         assert Mp2 == Mp
         dx = torch.empty(M, K, dtype=torch.float32, device=x.device) if ctx.needs_input_grad[0] else None
         if dx is not None:                                       # dx[M,K] = dy[M,N] . (W^T)[K,N]^T
-            _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
+            _nt_wgrad(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx, three, kmin=2048)
         _nt_wgrad(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW, three)   # dW[N,K] = (dy^T)[N,Mp] . (x^T)[K,Mp]^T
         if db is not None:                                       # second stage: the Mp / 32 block sums, in block order
             L.check(L.lib.ser_colsum(L.ptr(part), part.shape[0], N, N, L.ptr(db), 0, L.stream_ptr()), "ser_colsum")
@@ -299,7 +300,7 @@ class _LinearQKV(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
-            _nt(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx)
+            _nt_wgrad(_ptrs(dys, three), N, _ptrs(wt, three), Np, M, K, N, dx, three, kmin=2048)
         dW = torch.empty(N, K, dtype=torch.float32, device=dy.device)
         _nt_wgrad(_ptrs(dyt, three), Mp, _ptrs(xt, three), Mp, N, K, Mp, dW, three)
         db = torch.empty(N, dtype=torch.float32, device=dy.device)

@@ -375,15 +375,16 @@ def test_positional_conv_node_on_the_resident_slab_kernel(S):
         assert err < 2e-4 * max(1.0, want.abs().max().item()), f"{name}: {err:.3e} (max {want.abs().max().item():.3e})"
 
 
-@pytest.mark.parametrize("M", [1592, 3300])
-def test_tile_path_linear_and_conv_gradients_with_split_k(M):
+@pytest.mark.parametrize("M,N", [(1592, 192), (3300, 192), (1592, 2304)])
+def test_tile_path_linear_and_conv_gradients_with_split_k(M, N):
     """`_Linear` and `_ConvPad` on the MFMA tile kernel at row counts where the weight gradient's K range (the rows) is cut into
-    4 / 8 slices (`ser_gemm_bf16_nt_splitk` + slice-order sum): outputs and all gradients against float64."""
+    4 / 8 slices (`ser_gemm_bf16_nt_splitk` + slice-order sum), and at a layer width (2 304 outputs) where the input gradient's K
+    range is cut too: outputs and all gradients against float64."""
     import ser_amd  # noqa: F401
     from ser_amd.models._finetune import SLACK, _ConvPad, _Linear
     dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(M)
-    K, N = 256, 192
+    g = torch.Generator().manual_seed(M + N)
+    K = 256
     x, W, b, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     xg, Wg, bg = (t_.to(dev).requires_grad_() for t_ in (x, W, b))
     y = _Linear.apply(xg, Wg, bg, None)
