@@ -98,6 +98,9 @@ int ser_gemm_bf16_nt(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const 
  * for the fine-tuning encoders' weight gradients: long K (tokens, conv frames), small output. */
 int ser_gemm_bf16_nt_splitk(const uint16_t* a_hi, const uint16_t* a_lo, int lda, const uint16_t* w_hi, const uint16_t* w_lo, int ldw,
                             int M, int N, int K, int ksplit, float* slabs, void* stream);
+/* out[M*N] = the ks slabs added in slice order (+ bias[N] per row when given): the consumer of ser_gemm_bf16_nt_splitk for a product
+ * that carries a bias (the forward of a Linear layer with a long K) */
+int ser_sum_slabs_bias(const float* slabs, int ks, long long n, int N, const float* bias, float* out, void* stream);
 
 /* y = LayerNorm(x (+ x2)) * gamma + beta over the last dim D; fp32 in; fp32 and/or split out.
  * Replaces nn.LayerNorm in hf wav2vec2 :429,:601,:606 and xlm_roberta :336-340,:394-398. */

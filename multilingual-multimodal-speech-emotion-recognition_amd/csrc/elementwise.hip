@@ -230,6 +230,32 @@ extern "C" int ser_split_bf16_both_multi(const void* table, int nprob, long long
   return SER_OK;
 }
 
+// out[i] = slabs[0][i] + slabs[1][i] + ... (slice order) + bias[i % N]: the consumer of a split-K product that carries a bias
+__global__ void sum_slabs_bias_kernel(const float* __restrict__ slabs, int ks, long long n, int N, const float* __restrict__ bias,
+                                      float* __restrict__ out) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 a = *(const float4*)(slabs + i * 4);
+    for (int s = 1; s < ks; ++s) {
+      const float4 v = *(const float4*)(slabs + (long long)s * n + i * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    if (bias) {
+      const float4 bv = *(const float4*)(bias + (i * 4) % N);
+      a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+    }
+    *(float4*)(out + i * 4) = a;
+  }
+}
+extern "C" int ser_sum_slabs_bias(const float* slabs, int ks, long long n, int N, const float* bias, float* out, void* stream) {
+  SER_REQUIRE(slabs && out && ks >= 1 && n > 0 && n % 4 == 0 && N > 0 && N % 4 == 0 && n % N == 0, "sum_slabs_bias: bad arguments");
+  const long long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(sum_slabs_bias_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, slabs, ks, n, N,
+                     bias, out);
+  SER_LAUNCH_CHECK();
+  return SER_OK;
+}
+
 extern "C" int ser_split_bf16_both_colsum(const float* x, int R, int C, long long ldx, uint16_t* s_hi, uint16_t* s_lo, uint16_t* t_hi,
                                           uint16_t* t_lo, int Rp, float* colpart, void* stream) {
   SER_REQUIRE(x && s_hi && t_hi && R > 0 && C > 0 && C % SER_IL_GROUP == 0 && Rp >= R && Rp % SER_IL_GROUP == 0,

@@ -106,9 +106,10 @@ def _nt(a, lda, w, ldw, M, N, K, out, bias=None):
 
 
 L._sig("ser_gemm_bf16_nt_splitk", L.i32, L.vp, L.vp, L.i32, L.vp, L.vp, L.i32, L.i32, L.i32, L.i32, L.i32, L.vp, L.vp)
+L._sig("ser_sum_slabs_bias", L.i32, L.vp, L.i32, L.i64, L.i32, L.vp, L.vp, L.vp)
 
 
-def _nt_wgrad(a, lda, w, ldw, M, N, K, out, three, kmin=1024):
+def _nt_wgrad(a, lda, w, ldw, M, N, K, out, three, kmin=1024, bias=None):
     """out[M,N] = A[M,K] . W[N,K]^T for a product whose K is long and whose output is small - a weight gradient (K = tokens of the
     batch, or conv frames), or the input gradient of a wide layer (K = 2 304 / 3 072 output features, kmin = 2048).  In the
     three-product mode the K range is cut into slices on different workgroups (`ser_gemm_bf16_nt_splitk`) and the partial sums are
@@ -117,11 +118,14 @@ def _nt_wgrad(a, lda, w, ldw, M, N, K, out, three, kmin=1024):
     if three and K >= kmin:
         ks = 8 if K >= 3200 else 4
     if ks == 1:
-        return _nt(a, lda, w, ldw, M, N, K, out)
+        return _nt(a, lda, w, ldw, M, N, K, out, bias)
     slabs = torch.empty(ks, M * N, dtype=torch.float32, device=out.device)
     L.check(L.lib.ser_gemm_bf16_nt_splitk(a[0], a[1], int(lda), w[0], w[1], int(ldw), int(M), int(N), int(K), ks, slabs.data_ptr(),
                                           L.stream_ptr()), "ser_gemm_bf16_nt_splitk")
-    L.check(L.lib.ser_colsum(slabs.data_ptr(), ks, M * N, M * N, out.data_ptr(), 0, L.stream_ptr()), "ser_colsum")
+    if bias is not None:                                                      # a forward product: slices + bias in one pass
+        L.check(L.lib.ser_sum_slabs_bias(slabs.data_ptr(), ks, M * N, int(N), L.ptr(bias), out.data_ptr(), L.stream_ptr()), "ser_sum_slabs_bias")
+    else:
+        L.check(L.lib.ser_colsum(slabs.data_ptr(), ks, M * N, M * N, out.data_ptr(), 0, L.stream_ptr()), "ser_colsum")
 
 
 def _tile_ok(M, N, K):
@@ -229,7 +233,7 @@ class _Linear(torch.autograd.Function):
             else:
                 ws, wt, Np = L.split_bf16_both(W, three, three_b)
             ctx.planes_t = (xt, Mp, wt, Np, three_b)
-            _nt(_ptrs(xs, three), K, _ptrs(ws, three), K, M, N, K, y, b)
+            _nt_wgrad(_ptrs(xs, three), K, _ptrs(ws, three), K, M, N, K, y, three, kmin=2048, bias=b)   # (K = 3072: the FFN's second Linear)
             return y
         ctx.planes_t = None
         xs, ws = _planes(x, three), _planes(W, three)

@@ -394,6 +394,11 @@ def test_tile_path_linear_and_conv_gradients_with_split_k(M, N):
     assert (y.detach().cpu() - (x.double() @ W.double().t() + b.double()).float()).abs().max().item() < 5e-5      # three bf16 products per multiply
     for got, want, name in ((xg.grad, xd.grad, "dx"), (Wg.grad, Wd.grad, "dW"), (bg.grad, bd.grad, "db")):
         assert (got.cpu() - want.float()).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item()), name
+    # a long-K forward (the FFN's second Linear, K = 3072): split K + bias in the slice sum
+    K2 = 3072
+    x2, W2l, b2 = torch.randn(M, K2, generator=g), torch.randn(192, K2, generator=g) / K2 ** 0.5, torch.randn(192, generator=g)
+    y2 = _Linear.apply(x2.to(dev).requires_grad_(), W2l.to(dev).requires_grad_(), b2.to(dev).requires_grad_(), None)
+    assert (y2.detach().cpu() - (x2.double() @ W2l.double().t() + b2.double()).float()).abs().max().item() < 5e-5
     # conv: C_in = C_out = 64, kernel 3, stride 2 on one padded buffer
     Cin, Cout, k, s_ = 64, 64, 3, 2
     rows_out = M
